@@ -1,0 +1,242 @@
+/*
+ * pt.h — C ABI of the MI355X (gfx950) radiance inner loop.
+ *
+ * The reference (emimvi/pathtracer, Rust) has no FFI boundary; its seams are plain Rust
+ * signatures inside one crate.  Each entry point below names the Rust item it
+ * stands in for.  Everything here is plain C: pointers + sizes, no C++/torch types, so a Rust
+ * `extern "C"` block can bind it directly.
+ *
+ * Conventions
+ *   - return 0 (PT_OK) or a negative pt_status; never abort (the reference panics:
+ *     obj.rs:16, mipmap.rs:61/88, vec3.rs:256).  pt_last_error() gives the thread-local message.
+ *   - all input arrays are copied at create time; the caller keeps ownership.
+ *   - outputs are caller-owned buffers (host pointers, or device pointers for the *_device forms).
+ *   - a pt_scene is immutable after creation and may be used from several host threads.
+ *   - the HIP path is the only implementation: if no gfx950 device/code object is usable the
+ *     calls fail with PT_ERR_DEVICE (there is no CPU fallback).
+ */
+#ifndef PT_H
+#define PT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_MISS 0xFFFFFFFFu /* tri_id value for "no hit" (Option::None of scene.rs:61) */
+
+typedef enum pt_status {
+    PT_OK = 0,
+    PT_ERR_INVALID = -1,     /* bad argument / malformed scene */
+    PT_ERR_NOMEM = -2,       /* host or device allocation failed */
+    PT_ERR_DEVICE = -3,      /* HIP runtime error, or no usable device */
+    PT_ERR_IO = -4,          /* file could not be read / written */
+    PT_ERR_UNSUPPORTED = -5  /* e.g. non power-of-two texture (mipmap.rs:86-89 panics) */
+} pt_status;
+
+/* material kinds: material.rs:31-58 (Lambertian), microfacet.rs:9-94 (Glossy<Beckmann>) */
+enum { PT_MAT_LAMBERT = 0, PT_MAT_GLOSSY = 1 };
+
+/* One material.  Values arrive as f32 from the MTL parser and are widened to f64 exactly as
+ * obj.rs:66-69 does (Vec3::from([f32;3]), vec3.rs:187-191).
+ *   LAMBERT: color = Kd, emission = Ka (obj.rs:66-69); tex >= 0 replaces color by the mip-mapped
+ *            lookup of material.rs:100-111.
+ *   GLOSSY : color = reflectance (Kd), roughness = Beckmann width (Ns; clamped to >= 1e-5 by
+ *            microfacet.rs:125); emission is ignored (microfacet.rs:33-35 returns zero). */
+typedef struct pt_material {
+    float color[3];
+    float emission[3];
+    float roughness;
+    int32_t kind; /* PT_MAT_* */
+    int32_t tex;  /* index into pt_scene_desc.texs, or -1 */
+} pt_material;
+
+/* 8-bit RGB image, tightly packed, top row first (the order image::open(..).to_rgb() yields,
+ * mipmap.rs:60-74).  Width and height must be powers of two (mipmap.rs:86-89). */
+typedef struct pt_texture {
+    uint32_t width, height;
+    const uint8_t* rgb8;
+} pt_texture;
+
+/* scene.rs:20-35 Camera */
+typedef struct pt_camera {
+    double eye[3];
+    double view[3];
+    double up[3];
+    double camera_const;
+} pt_camera;
+
+/* Flattened two-child BVH node (64 B = four 16-byte loads).  bounds = {lo0,hi0,lo1,hi1} of the
+ * two children, f32 like the reference's external bvh crate (bvh.rs:37,98-101), padded outward
+ * by the builder so an f64 slab test never culls a triangle the f64 triangle test accepts.
+ * child >= 0: index of an inner node.  child < 0: leaf, ~child = (first << 3) | (count - 1),
+ * a run of `count` (1..8) entries of bvh_tri_order.  PT_BVH_EMPTY: no child. */
+#define PT_BVH_EMPTY 0x7FFFFFFF
+typedef struct pt_bvh_node {
+    float bounds[12];
+    int32_t child[2];
+    uint32_t pad[2];
+} pt_bvh_node;
+
+/* Flat scene = what scene.rs:13-18 + obj.rs:13-107 + triangle_mesh.rs:12-57 hold, with the
+ * per-model TriMesh/Geometry boxes flattened into one triangle list in OBJ model/face order
+ * (there is no instancing in the reference). */
+typedef struct pt_scene_desc {
+    const float* verts;           /* [n_verts][3] positions, f32 as tobj delivers them (obj.rs:22-27) */
+    uint32_t n_verts;
+    const uint32_t* tris;         /* [n_tris][3] vertex ids */
+    uint32_t n_tris;
+    const float* tri_uvs;         /* [n_tris][3][2] or NULL = (0,0),(1,0),(1,1) for every triangle
+                                     (triangle_mesh.rs:92-94) */
+    const uint32_t* tri_material; /* [n_tris] index into mats */
+    const pt_material* mats;
+    uint32_t n_mats;
+    const pt_texture* texs;
+    uint32_t n_texs;
+    pt_camera camera;
+    double background[3];         /* scene.rs:16 */
+    /* optional BVH built by the caller (the host side owns the build, bvh.rs:17-21);
+     * NULL => the library runs its own binned-SAH builder (pt_bvh_build). */
+    const pt_bvh_node* bvh_nodes;
+    uint32_t n_bvh_nodes;
+    const uint32_t* bvh_tri_order; /* [n_tris] triangle ids in leaf order */
+} pt_scene_desc;
+
+/* geometry/ray.rs:5-14 without the differential rays (those are rebuilt from the pixel, §DESIGN) */
+typedef struct pt_ray {
+    double o[3];
+    double d[3];
+    double t_min; /* Ray::new uses 1e-5 (ray.rs:21) */
+    double t_max; /* Ray::new uses f64::MAX (ray.rs:22) */
+} pt_ray;
+
+enum {
+    PT_FLAG_USE_DIFFS = 1u << 0, /* CONFIG.use_diffs, default true (main.rs:350) */
+    PT_FLAG_NEE = 1u << 1,       /* next-event estimation against emissive triangles (+MIS) */
+    PT_FLAG_DROP_NONFINITE = 1u << 2 /* drop NaN/inf samples instead of accumulating them
+                                        (deviation from main.rs:434-436; off by default) */
+};
+
+/* CONFIG of main.rs:320-379 plus the partitioning knobs of SURVEY.md §8e. */
+typedef struct pt_render_params {
+    uint32_t width, height;   /* full image; reference is square dim x dim (main.rs:382-383) */
+    uint32_t x0, y0, x1, y1;  /* tile [x0,x1) x [y0,y1) rendered by this call */
+    uint64_t sample_begin;    /* first frame index (main.rs:400 loop iteration, 0-based) */
+    uint32_t sample_count;    /* number of frames = samples per pixel added by this call */
+    uint32_t max_bounces;     /* CONFIG.bounces, default 2 (main.rs:347) */
+    uint32_t flags;           /* PT_FLAG_* */
+    uint32_t spp_per_batch;   /* frames kept in flight per wavefront pass; 0 = auto */
+    uint64_t seed;            /* key of the counter-based RNG that replaces rand::random (F8) */
+} pt_render_params;
+
+typedef struct pt_kernel_stat {
+    uint64_t launches;
+    double ms; /* summed HIP-event time */
+} pt_kernel_stat;
+
+enum { PT_K_GENERATE = 0, PT_K_EXTEND, PT_K_SHADE, PT_K_SHADOW, PT_K_ACCUMULATE, PT_K_COUNT };
+
+typedef struct pt_stats {
+    uint64_t samples;        /* render() calls (main.rs:283) */
+    uint64_t rays;           /* trace_closest calls (scene.rs:61) */
+    uint64_t shadow_rays;    /* trace_any calls (scene.rs:66) */
+    uint64_t nodes_visited;  /* child boxes slab-tested (32 B each); only with pt_set_profiling(..,2) */
+    uint64_t tris_tested;    /* Triangle::intersect calls (triangle_mesh.rs:101) */
+    pt_kernel_stat kernel[PT_K_COUNT];
+} pt_stats;
+
+typedef struct pt_scene pt_scene;
+
+/* ---- scene.rs:140-193 + bvh.rs:17-21: build the device-resident scene on HIP device `device_id` */
+int pt_scene_create(const pt_scene_desc* desc, int device_id, pt_scene** out);
+void pt_scene_destroy(pt_scene* scene);
+/* introspection (host copies owned by the scene, valid until destroy) */
+int pt_scene_get_bvh(const pt_scene* scene, const pt_bvh_node** nodes, uint32_t* n_nodes,
+                     const uint32_t** tri_order, uint32_t* max_depth);
+
+/* ---- bvh.rs:17-21 `e_BVH::unanimated(8, ..)`: host-side binned-SAH build (the external crate
+ * is not vendored).  nodes_out has room for `cap_nodes` (>= max(1, n_tris)) nodes,
+ * order_out for n_tris ids.  max_leaf in 1..8. */
+int pt_bvh_build(const float* verts, uint32_t n_verts, const uint32_t* tris, uint32_t n_tris,
+                 uint32_t max_leaf, pt_bvh_node* nodes_out, uint32_t cap_nodes,
+                 uint32_t* n_nodes_out, uint32_t* order_out, uint32_t* max_depth_out);
+
+/* ---- scene.rs:61 Scene::trace_closest on an explicit ray set (the extend kernel alone).
+ * tri_id[i] = global triangle id (desc order) or PT_MISS; t[i] = hit distance (unchanged t_max on a miss).
+ * Tie rule for bit-identical t: lowest triangle id. */
+int pt_trace_closest(pt_scene* scene, const pt_ray* rays, size_t n, uint32_t* tri_id, double* t);
+
+/* ---- main.rs:402-427 + scene.rs:37-57: the generate kernel alone.  Writes the primary rays of
+ * frame `sample` for the tile pixels in row-major tile order (rays[(y-y0)*(x1-x0) + (x-x0)]). */
+int pt_generate_rays(pt_scene* scene, const pt_render_params* params, uint64_t sample,
+                     pt_ray* rays);
+
+/* ---- material.rs:60-66 `_Material::sample_brdf` + get_emission at given hits (the shade
+ * kernel's sampling step alone).  For ray i that hit triangle tri_id[i] at distance t[i], with
+ * RNG counters (pixel[i], sample, bounce): f[i], wi[i], pdf[i], emission[i], position[i]. */
+int pt_sample_brdf(pt_scene* scene, const pt_ray* rays, const uint32_t* tri_id, const double* t,
+                   const uint32_t* pixel, size_t n, uint64_t sample, uint32_t bounce,
+                   uint64_t seed, uint32_t flags, uint32_t width, uint32_t height,
+                   double* f /*[n][3]*/, double* wi /*[n][3]*/, double* pdf /*[n]*/,
+                   double* emission /*[n][3]*/, double* position /*[n][3]*/);
+
+/* ---- mipmap.rs:117-141 MipMap::sample_mipmap on texture `tex` of the scene. */
+int pt_texture_lookup(pt_scene* scene, uint32_t tex, const double* uv /*[n][2]*/,
+                      const double* duvdx /*[n][2]*/, const double* duvdy /*[n][2]*/, size_t n,
+                      double* rgb /*[n][3]*/);
+
+/* ---- main.rs:400-436: sample_count frames of the tile, accum[(y*width+x)*3+c] += radiance
+ * (f64, the `pixels[i] += next[i]` of main.rs:434-436, frames added in index order).
+ * pt_render: accum is a host buffer of width*height*3 doubles.
+ * pt_render_device: accum is a device buffer on the scene's device; work is enqueued on `stream`
+ * (a hipStream_t, NULL = default stream) and the call returns after enqueueing unless profiling
+ * is on.  */
+int pt_render(pt_scene* scene, const pt_render_params* params, double* accum_rgb);
+int pt_render_device(pt_scene* scene, const pt_render_params* params, double* accum_rgb_dev,
+                     void* stream);
+
+/* ---- main.rs:456-467 get_raw_pixels_u32 / mipmap.rs:21-23 f64_to_8bit_color:
+ * rgb8[i] = clamp(accum[i] / iterations) * 255 + 0.5 truncated; no gamma. (host) */
+int pt_resolve_rgb8(const double* accum_rgb, size_t n_pixels, uint64_t iterations, uint8_t* rgb8);
+/* ---- mipmap.rs:25-42 Image::save_ppm: ASCII P3, one pixel per line. */
+int pt_write_ppm(const char* path, uint32_t width, uint32_t height, const uint8_t* rgb8);
+
+/* profiling: level 0 = off, 1 = HIP-event time per kernel launch, 2 = also count BVH nodes
+ * visited / triangles tested (instrumented extend kernel; slower). */
+int pt_set_profiling(pt_scene* scene, int level);
+int pt_get_stats(pt_scene* scene, pt_stats* out);
+int pt_reset_stats(pt_scene* scene);
+
+/* ---- obj.rs:13-107 load_obj with tobj 0.1.6 semantics, host side.
+ * Returns an owned model; pt_model_desc() exposes it as a pt_scene_desc (camera/background are
+ * zeroed: set them before pt_scene_create, scene.rs:184-186). */
+typedef struct pt_model pt_model;
+int pt_load_obj(const char* obj_path, uint32_t flags, pt_model** out);
+enum {
+    PT_LOAD_GLOSSY = 1u << 0,   /* wire illum 2 -> Glossy(Ns) as the commented obj.rs:30-53 intends */
+    PT_LOAD_TEXTURES = 1u << 1  /* wire map_Kd -> MipMap (obj.rs:41-47) */
+};
+const pt_scene_desc* pt_model_desc(const pt_model* model);
+uint32_t pt_model_count(const pt_model* model);               /* tobj models (= reference Geometry count) */
+const char* pt_model_name(const pt_model* model, uint32_t i);
+uint32_t pt_model_first_tri(const pt_model* model, uint32_t i); /* first global triangle of model i */
+void pt_model_destroy(pt_model* model);
+
+/* ---- mipmap.rs:59-83 MipMap::load decode step for PNG (8-bit RGB/RGBA/gray, non-interlaced). */
+int pt_decode_png(const char* path, uint32_t* width, uint32_t* height, uint8_t** rgb8_out);
+void pt_free(void* p);
+
+/* counter-based RNG that replaces rand::random::<f64>(): Philox4x32-10,
+ * key = seed, counter = (pixel, sample_lo, bounce | sample_hi << 8 .., stream). Exposed for tests. */
+void pt_rng_uniform2(uint64_t seed, uint32_t pixel, uint64_t sample, uint32_t bounce,
+                     uint32_t stream, double out[2]);
+
+const char* pt_last_error(void);
+const char* pt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_H */

@@ -1,0 +1,138 @@
+"""ctypes binding of include/pt.h (libpt_hip.so).
+
+The shared library is the product: there is no Python or CPU implementation behind these calls.
+If the in-tree library is missing the import fails loudly (build it with
+``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C pathtracer_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpt_hip.so")
+
+PT_MISS = 0xFFFFFFFF
+PT_OK, PT_ERR_INVALID, PT_ERR_NOMEM, PT_ERR_DEVICE, PT_ERR_IO, PT_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+PT_MAT_LAMBERT, PT_MAT_GLOSSY = 0, 1
+PT_BVH_EMPTY = 0x7FFFFFFF
+PT_FLAG_USE_DIFFS, PT_FLAG_NEE, PT_FLAG_DROP_NONFINITE = 1, 2, 4
+PT_LOAD_GLOSSY, PT_LOAD_TEXTURES = 1, 2
+PT_K_GENERATE, PT_K_EXTEND, PT_K_SHADE, PT_K_SHADOW, PT_K_ACCUMULATE, PT_K_COUNT = 0, 1, 2, 3, 4, 5
+KERNEL_NAMES = ("generate", "extend", "shade", "shadow", "accumulate")
+
+
+class pt_material(C.Structure):
+    _fields_ = [("color", C.c_float * 3), ("emission", C.c_float * 3), ("roughness", C.c_float),
+                ("kind", C.c_int32), ("tex", C.c_int32)]
+
+
+class pt_texture(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("rgb8", C.POINTER(C.c_uint8))]
+
+
+class pt_camera(C.Structure):
+    _fields_ = [("eye", C.c_double * 3), ("view", C.c_double * 3), ("up", C.c_double * 3),
+                ("camera_const", C.c_double)]
+
+
+class pt_bvh_node(C.Structure):
+    _fields_ = [("bounds", C.c_float * 12), ("child", C.c_int32 * 2), ("pad", C.c_uint32 * 2)]
+
+
+class pt_scene_desc(C.Structure):
+    _fields_ = [("verts", C.POINTER(C.c_float)), ("n_verts", C.c_uint32),
+                ("tris", C.POINTER(C.c_uint32)), ("n_tris", C.c_uint32),
+                ("tri_uvs", C.POINTER(C.c_float)),
+                ("tri_material", C.POINTER(C.c_uint32)),
+                ("mats", C.POINTER(pt_material)), ("n_mats", C.c_uint32),
+                ("texs", C.POINTER(pt_texture)), ("n_texs", C.c_uint32),
+                ("camera", pt_camera), ("background", C.c_double * 3),
+                ("bvh_nodes", C.POINTER(pt_bvh_node)), ("n_bvh_nodes", C.c_uint32),
+                ("bvh_tri_order", C.POINTER(C.c_uint32))]
+
+
+class pt_ray(C.Structure):
+    _fields_ = [("o", C.c_double * 3), ("d", C.c_double * 3), ("t_min", C.c_double), ("t_max", C.c_double)]
+
+
+class pt_render_params(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32),
+                ("x0", C.c_uint32), ("y0", C.c_uint32), ("x1", C.c_uint32), ("y1", C.c_uint32),
+                ("sample_begin", C.c_uint64), ("sample_count", C.c_uint32),
+                ("max_bounces", C.c_uint32), ("flags", C.c_uint32), ("spp_per_batch", C.c_uint32),
+                ("seed", C.c_uint64)]
+
+
+class pt_kernel_stat(C.Structure):
+    _fields_ = [("launches", C.c_uint64), ("ms", C.c_double)]
+
+
+class pt_stats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("shadow_rays", C.c_uint64),
+                ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
+                ("kernel", pt_kernel_stat * PT_K_COUNT)]
+
+
+# every symbol include/pt.h declares: name -> (restype, argtypes)
+_P = C.POINTER
+_vp = C.c_void_p
+PROTOTYPES = {
+    "pt_scene_create": (C.c_int, [_P(pt_scene_desc), C.c_int, _P(_vp)]),
+    "pt_scene_destroy": (None, [_vp]),
+    "pt_scene_get_bvh": (C.c_int, [_vp, _P(_P(pt_bvh_node)), _P(C.c_uint32), _P(_P(C.c_uint32)), _P(C.c_uint32)]),
+    "pt_bvh_build": (C.c_int, [_P(C.c_float), C.c_uint32, _P(C.c_uint32), C.c_uint32, C.c_uint32,
+                               _P(pt_bvh_node), C.c_uint32, _P(C.c_uint32), _P(C.c_uint32), _P(C.c_uint32)]),
+    "pt_trace_closest": (C.c_int, [_vp, _P(pt_ray), C.c_size_t, _P(C.c_uint32), _P(C.c_double)]),
+    "pt_generate_rays": (C.c_int, [_vp, _P(pt_render_params), C.c_uint64, _P(pt_ray)]),
+    "pt_sample_brdf": (C.c_int, [_vp, _P(pt_ray), _P(C.c_uint32), _P(C.c_double), _P(C.c_uint32), C.c_size_t,
+                                 C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                 _P(C.c_double), _P(C.c_double), _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
+    "pt_texture_lookup": (C.c_int, [_vp, C.c_uint32, _P(C.c_double), _P(C.c_double), _P(C.c_double), C.c_size_t,
+                                    _P(C.c_double)]),
+    "pt_render": (C.c_int, [_vp, _P(pt_render_params), _P(C.c_double)]),
+    "pt_render_device": (C.c_int, [_vp, _P(pt_render_params), _vp, _vp]),
+    "pt_resolve_rgb8": (C.c_int, [_P(C.c_double), C.c_size_t, C.c_uint64, _P(C.c_uint8)]),
+    "pt_write_ppm": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, _P(C.c_uint8)]),
+    "pt_set_profiling": (C.c_int, [_vp, C.c_int]),
+    "pt_get_stats": (C.c_int, [_vp, _P(pt_stats)]),
+    "pt_reset_stats": (C.c_int, [_vp]),
+    "pt_load_obj": (C.c_int, [C.c_char_p, C.c_uint32, _P(_vp)]),
+    "pt_model_desc": (_P(pt_scene_desc), [_vp]),
+    "pt_model_count": (C.c_uint32, [_vp]),
+    "pt_model_name": (C.c_char_p, [_vp, C.c_uint32]),
+    "pt_model_first_tri": (C.c_uint32, [_vp, C.c_uint32]),
+    "pt_model_destroy": (None, [_vp]),
+    "pt_decode_png": (C.c_int, [C.c_char_p, _P(C.c_uint32), _P(C.c_uint32), _P(_P(C.c_uint8))]),
+    "pt_free": (None, [_vp]),
+    "pt_rng_uniform2": (None, [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, _P(C.c_double)]),
+    "pt_last_error": (C.c_char_p, []),
+    "pt_version": (C.c_char_p, []),
+}
+
+
+class PtError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"pt error {code}: {message}")
+        self.code = code
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP library is the only implementation of pathtracer_amd "
+            "(no CPU fallback). Build it with `make -C pathtracer_amd/csrc` or __graft_entry__.build().")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int) -> None:
+    if rc != PT_OK:
+        raise PtError(rc, (lib.pt_last_error() or b"").decode("utf-8", "replace"))

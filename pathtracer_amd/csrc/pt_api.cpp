@@ -1,0 +1,715 @@
+// pt_api.cpp — the C ABI of include/pt.h: scene upload, the wavefront render loop and the parity
+// entry points.  Host-side orchestration only; all radiance arithmetic runs in pt_kernels.hip.
+// There is deliberately no CPU fallback: without a usable HIP device every compute call fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "pt_device.h"
+#include "pt_host.h"
+
+using pth::set_error;
+
+#define HIP_TRY(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return PT_ERR_DEVICE;                                                        \
+        }                                                                                \
+    } while (0)
+
+namespace {
+
+struct DeviceGuard {  // make the scene's device current for the duration of a call
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+struct DevBuf {  // owning device allocation
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    hipError_t alloc(size_t n) {
+        release();
+        if (n == 0) n = 16;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n; else p = nullptr;
+        return e;
+    }
+    template <class T>
+    T* as() const { return (T*)p; }
+};
+
+struct Carver {  // carves 256-byte aligned arrays out of one allocation
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* b) : base((char*)b) {}
+    template <class T>
+    T* take(size_t n) {
+        size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
+        T* r = base ? (T*)(base + off) : nullptr;
+        off += bytes;
+        return r;
+    }
+};
+
+constexpr uint32_t kMaxBounces = 61;  // counters[] holds one queue counter per bounce
+constexpr uint32_t kCounterWords = 128;
+
+struct Workspace {
+    DevBuf buf;
+    uint32_t cap_slots = 0;
+    bool nee = false;
+    ptd::Queue q[2];
+    ptd::Hits hits;
+    ptd::ShadowQueue sq;
+    ptd::Sample3 ls;
+    uint32_t* counters = nullptr;  // [0..63] path queue counts per bounce, [64..127] shadow queue counts
+    DevBuf jitter;
+    uint64_t jitter_cap = 0;
+};
+
+void carve_workspace(Workspace& w, void* base, uint32_t slots, bool nee, size_t& total) {
+    Carver c(base);
+    for (int k = 0; k < 2; ++k) {
+        for (int a = 0; a < 3; ++a) w.q[k].o[a] = c.take<double>(slots);
+        for (int a = 0; a < 3; ++a) w.q[k].d[a] = c.take<double>(slots);
+        for (int a = 0; a < 3; ++a) w.q[k].T[a] = c.take<double>(slots);
+        w.q[k].prev_pdf = nee ? c.take<double>(slots) : nullptr;
+        w.q[k].slot = c.take<uint32_t>(slots);
+    }
+    w.hits.tri = c.take<uint32_t>(slots);
+    w.hits.t = c.take<double>(slots);
+    for (int a = 0; a < 3; ++a) w.ls.c[a] = c.take<double>(slots);
+    if (nee) {
+        for (int a = 0; a < 3; ++a) w.sq.o[a] = c.take<double>(slots);
+        for (int a = 0; a < 3; ++a) w.sq.d[a] = c.take<double>(slots);
+        w.sq.tmax = c.take<double>(slots);
+        for (int a = 0; a < 3; ++a) w.sq.c[a] = c.take<double>(slots);
+        w.sq.slot = c.take<uint32_t>(slots);
+    } else {
+        std::memset(&w.sq, 0, sizeof w.sq);
+    }
+    w.counters = c.take<uint32_t>(kCounterWords);
+    total = c.off;
+}
+
+struct TimedLaunch {
+    int kind;
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct pt_scene {
+    int device = 0;
+    uint32_t n_tris = 0, n_texs = 0, n_mats = 0;
+    std::vector<pt_bvh_node> nodes;
+    std::vector<uint32_t> order;
+    uint32_t depth = 0;
+    ptd::Scene dev{};
+    DevBuf d_nodes, d_tris, d_uvs, d_leaf_of, d_mats, d_texs, d_lights, d_ctr;
+    std::vector<DevBuf*> d_texels;
+    Workspace ws;
+    std::mutex mu;
+    int profiling = 0;
+    pt_stats stats{};
+    std::vector<TimedLaunch> timed;
+    std::vector<hipEvent_t> event_pool;
+    ~pt_scene() {
+        for (auto* b : d_texels) delete b;
+        for (auto e : event_pool) (void)hipEventDestroy(e);
+        for (auto& t : timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    }
+};
+
+namespace {
+
+// host-side f64 helpers for the camera basis (scene.rs:38-42), same operation order as vec3.rs
+struct H3 {
+    double x, y, z;
+};
+H3 hcross(H3 a, H3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+H3 hnorm(H3 a) {
+    double l = std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
+    return {a.x / l, a.y / l, a.z / l};
+}
+H3 hneg(H3 a) { return {-a.x, -a.y, -a.z}; }
+
+template <class T>
+int upload(DevBuf& b, const T* src, size_t n) {
+    HIP_TRY(b.alloc(std::max<size_t>(n, 1) * sizeof(T)));
+    if (n) HIP_TRY(hipMemcpy(b.p, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return PT_OK;
+}
+
+int ensure_workspace(pt_scene* s, uint32_t slots, bool nee) {
+    Workspace& w = s->ws;
+    if (w.buf.p && w.cap_slots >= slots && (w.nee || !nee)) return PT_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    w.buf.release();
+    size_t total = 0;
+    Workspace probe;
+    carve_workspace(probe, nullptr, slots, nee, total);
+    hipError_t e = w.buf.alloc(total);
+    if (e != hipSuccess) {
+        w.cap_slots = 0;
+        set_error("workspace allocation of %zu bytes failed: %s", total, hipGetErrorString(e));
+        return PT_ERR_NOMEM;
+    }
+    carve_workspace(w, w.buf.p, slots, nee, total);
+    w.cap_slots = slots;
+    w.nee = nee;
+    return PT_OK;
+}
+
+struct Timer {  // optional HIP-event bracket around one kernel launch
+    pt_scene* s;
+    hipStream_t st;
+    int kind;
+    bool on;
+    hipEvent_t a{}, b{};
+    Timer(pt_scene* s_, hipStream_t st_, int kind_) : s(s_), st(st_), kind(kind_), on(s_->profiling >= 1) {
+        if (!on) return;
+        auto get = [&](hipEvent_t& e) {
+            if (!s->event_pool.empty()) { e = s->event_pool.back(); s->event_pool.pop_back(); return true; }
+            return hipEventCreate(&e) == hipSuccess;
+        };
+        on = get(a) && get(b);
+        if (on) (void)hipEventRecord(a, st);
+    }
+    ~Timer() {
+        if (!on) return;
+        (void)hipEventRecord(b, st);
+        s->timed.push_back({kind, a, b});
+    }
+};
+
+int collect_timers(pt_scene* s, hipStream_t st) {
+    if (s->timed.empty()) return PT_OK;
+    HIP_TRY(hipStreamSynchronize(st));
+    for (auto& t : s->timed) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+            s->stats.kernel[t.kind].launches += 1;
+            s->stats.kernel[t.kind].ms += (double)ms;
+        }
+        s->event_pool.push_back(t.a);
+        s->event_pool.push_back(t.b);
+    }
+    s->timed.clear();
+    return PT_OK;
+}
+
+int check_params(const pt_render_params* p) {
+    if (!p) { set_error("null params"); return PT_ERR_INVALID; }
+    if (p->width == 0 || p->height == 0 || (uint64_t)p->width * p->height >= (1ull << 32)) {
+        set_error("bad image size %ux%u", p->width, p->height);
+        return PT_ERR_INVALID;
+    }
+    if (p->x0 >= p->x1 || p->y0 >= p->y1 || p->x1 > p->width || p->y1 > p->height) {
+        set_error("bad tile [%u,%u)x[%u,%u) for %ux%u", p->x0, p->x1, p->y0, p->y1, p->width, p->height);
+        return PT_ERR_INVALID;
+    }
+    if (p->max_bounces > kMaxBounces) { set_error("max_bounces > %u", kMaxBounces); return PT_ERR_UNSUPPORTED; }
+    if ((uint64_t)(p->x1 - p->x0) * (p->y1 - p->y0) > (1ull << 30)) { set_error("tile too large"); return PT_ERR_UNSUPPORTED; }
+    return PT_OK;
+}
+
+}  // namespace
+
+namespace ptd {
+void launch_jitter(uint64_t seed, uint64_t sample_begin, uint32_t n, double psx, double psy, double* out, hipStream_t st);
+}
+
+extern "C" {
+
+int pt_bvh_build(const float* verts, uint32_t n_verts, const uint32_t* tris, uint32_t n_tris, uint32_t max_leaf,
+                 pt_bvh_node* nodes_out, uint32_t cap_nodes, uint32_t* n_nodes_out, uint32_t* order_out,
+                 uint32_t* max_depth_out) {
+    if ((n_tris && (!verts || !tris)) || !nodes_out || !n_nodes_out || (n_tris && !order_out)) {
+        set_error("null argument");
+        return PT_ERR_INVALID;
+    }
+    std::vector<pt_bvh_node> nodes;
+    std::vector<uint32_t> order;
+    uint32_t depth = 0;
+    int rc = pth::bvh_build(verts, n_verts, tris, n_tris, max_leaf, nodes, order, depth);
+    if (rc != PT_OK) { set_error("bvh build failed (bad index, non-finite vertex or max_leaf)"); return rc; }
+    if (nodes.size() > cap_nodes) { set_error("nodes_out too small: need %zu", nodes.size()); return PT_ERR_INVALID; }
+    std::memcpy(nodes_out, nodes.data(), nodes.size() * sizeof(pt_bvh_node));
+    if (n_tris) std::memcpy(order_out, order.data(), order.size() * sizeof(uint32_t));
+    *n_nodes_out = (uint32_t)nodes.size();
+    if (max_depth_out) *max_depth_out = depth;
+    return PT_OK;
+}
+
+int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
+    if (!d || !out) { set_error("null argument"); return PT_ERR_INVALID; }
+    *out = nullptr;
+    if (d->n_tris && (!d->verts || !d->tris)) { set_error("verts/tris missing"); return PT_ERR_INVALID; }
+    if (d->n_tris && d->n_mats == 0) { set_error("scene has triangles but no materials"); return PT_ERR_INVALID; }
+    if ((d->n_mats && !d->mats) || (d->n_texs && !d->texs)) { set_error("mats/texs missing"); return PT_ERR_INVALID; }
+    for (uint32_t i = 0; i < d->n_mats; ++i) {
+        const pt_material& m = d->mats[i];
+        if (m.kind != PT_MAT_LAMBERT && m.kind != PT_MAT_GLOSSY) { set_error("material %u: bad kind", i); return PT_ERR_INVALID; }
+        if (m.tex >= (int32_t)d->n_texs) { set_error("material %u: texture index out of range", i); return PT_ERR_INVALID; }
+    }
+    for (uint32_t i = 0; i < d->n_tris; ++i) {
+        if (d->tri_material && d->tri_material[i] >= d->n_mats) { set_error("triangle %u: material out of range", i); return PT_ERR_INVALID; }
+        for (int k = 0; k < 3; ++k)
+            if (d->tris[3 * i + k] >= d->n_verts) { set_error("triangle %u: vertex out of range", i); return PT_ERR_INVALID; }
+    }
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
+        set_error("no HIP device available (the HIP path is the only implementation)");
+        return PT_ERR_DEVICE;
+    }
+    if (device_id < 0 || device_id >= n_dev) { set_error("device %d out of range (%d devices)", device_id, n_dev); return PT_ERR_INVALID; }
+
+    std::unique_ptr<pt_scene> s(new pt_scene());
+    s->device = device_id;
+    s->n_tris = d->n_tris;
+    s->n_texs = d->n_texs;
+    s->n_mats = d->n_mats;
+
+    // ---- BVH: the caller's, or our own (bvh.rs:17-21)
+    if (d->bvh_nodes) {
+        if (!d->bvh_tri_order && d->n_tris) { set_error("bvh_nodes given without bvh_tri_order"); return PT_ERR_INVALID; }
+        s->nodes.assign(d->bvh_nodes, d->bvh_nodes + d->n_bvh_nodes);
+        s->order.assign(d->bvh_tri_order, d->bvh_tri_order + d->n_tris);
+    } else {
+        int rc = pth::bvh_build(d->verts, d->n_verts, d->tris, d->n_tris, 4, s->nodes, s->order, s->depth);
+        if (rc != PT_OK) { set_error("bvh build failed (non-finite vertex?)"); return rc; }
+    }
+    {
+        std::string why;
+        uint32_t depth = 0;
+        int rc = pth::bvh_validate(s->nodes.data(), (uint32_t)s->nodes.size(), s->order.data(), d->n_tris,
+                                   (uint32_t)ptd::kStackDepth, depth, why);
+        if (rc != PT_OK) { set_error("invalid BVH: %s", why.c_str()); return rc; }
+        std::vector<uint8_t> seen(d->n_tris, 0);
+        for (uint32_t i = 0; i < d->n_tris; ++i) {
+            if (seen[s->order[i]]) { set_error("invalid BVH: triangle %u listed twice", s->order[i]); return PT_ERR_INVALID; }
+            seen[s->order[i]] = 1;
+        }
+        s->depth = depth;
+    }
+
+    DeviceGuard guard(device_id);
+    if (!guard.ok) { set_error("hipSetDevice(%d) failed", device_id); return PT_ERR_DEVICE; }
+
+    // ---- triangles in leaf order, 3 x float4 each
+    std::vector<float> tri4((size_t)d->n_tris * 12);
+    std::vector<float> uv6;
+    std::vector<uint32_t> leaf_of(d->n_tris);
+    if (d->tri_uvs) uv6.resize((size_t)d->n_tris * 6);
+    for (uint32_t leaf = 0; leaf < d->n_tris; ++leaf) {
+        uint32_t g = s->order[leaf];
+        leaf_of[g] = leaf;
+        uint32_t mat = d->tri_material ? d->tri_material[g] : 0;
+        for (int k = 0; k < 3; ++k) {
+            const float* v = d->verts + 3 * (size_t)d->tris[3 * g + k];
+            float* dst = &tri4[(size_t)leaf * 12 + k * 4];
+            dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2];
+            uint32_t w = k == 0 ? g : (k == 1 ? mat : 0u);
+            std::memcpy(&dst[3], &w, 4);
+        }
+        if (d->tri_uvs) std::memcpy(&uv6[(size_t)leaf * 6], d->tri_uvs + (size_t)g * 6, 6 * sizeof(float));
+    }
+    int rc;
+    if ((rc = upload(s->d_nodes, s->nodes.data(), s->nodes.size())) != PT_OK) return rc;
+    if ((rc = upload(s->d_tris, tri4.data(), tri4.size())) != PT_OK) return rc;
+    if ((rc = upload(s->d_leaf_of, leaf_of.data(), leaf_of.size())) != PT_OK) return rc;
+    if (d->tri_uvs && (rc = upload(s->d_uvs, uv6.data(), uv6.size())) != PT_OK) return rc;
+
+    // ---- materials (f32 -> f64 widening of obj.rs:66-69)
+    std::vector<ptd::Material> mats(d->n_mats);
+    for (uint32_t i = 0; i < d->n_mats; ++i) {
+        const pt_material& m = d->mats[i];
+        for (int c = 0; c < 3; ++c) { mats[i].color[c] = (double)m.color[c]; mats[i].emission[c] = (double)m.emission[c]; }
+        mats[i].width = std::fmax((double)m.roughness, 1e-5);  // microfacet.rs:125
+        mats[i].kind = m.kind;
+        mats[i].tex = m.tex;
+    }
+    if ((rc = upload(s->d_mats, mats.data(), mats.size())) != PT_OK) return rc;
+
+    // ---- textures: f64 pyramids (mipmap.rs:85-98)
+    std::vector<ptd::Texture> texs(d->n_texs);
+    for (uint32_t i = 0; i < d->n_texs; ++i) {
+        std::vector<double> texels;
+        std::vector<uint32_t> offset;
+        rc = pth::build_pyramid(d->texs[i], texels, offset);
+        if (rc != PT_OK) return rc;
+        DevBuf* b = new DevBuf();
+        s->d_texels.push_back(b);
+        if ((rc = upload(*b, texels.data(), texels.size())) != PT_OK) return rc;
+        std::memset(&texs[i], 0, sizeof texs[i]);
+        texs[i].texels = b->as<double>();
+        texs[i].n_levels = (uint32_t)offset.size();
+        texs[i].width0 = d->texs[i].width;
+        texs[i].height0 = d->texs[i].height;
+        for (size_t l = 0; l < offset.size(); ++l) texs[i].offset[l] = offset[l];
+    }
+    if ((rc = upload(s->d_texs, texs.data(), texs.size())) != PT_OK) return rc;
+
+    // ---- lights for NEE: emissive triangles in global id order, area CDF
+    std::vector<ptd::Light> lights;
+    double acc = 0.;
+    for (uint32_t g = 0; g < d->n_tris; ++g) {
+        const ptd::Material& m = mats[d->tri_material ? d->tri_material[g] : 0];
+        if (m.kind == PT_MAT_GLOSSY) continue;
+        if (m.emission[0] == 0. && m.emission[1] == 0. && m.emission[2] == 0.) continue;
+        H3 v[3];
+        for (int k = 0; k < 3; ++k) {
+            const float* p = d->verts + 3 * (size_t)d->tris[3 * g + k];
+            v[k] = {(double)p[0], (double)p[1], (double)p[2]};
+        }
+        H3 e1{v[1].x - v[0].x, v[1].y - v[0].y, v[1].z - v[0].z}, e2{v[2].x - v[0].x, v[2].y - v[0].y, v[2].z - v[0].z};
+        H3 c = hcross(e1, e2);
+        double area = 0.5 * std::sqrt(c.x * c.x + c.y * c.y + c.z * c.z);
+        if (!(area > 0.)) continue;
+        acc += area;
+        ptd::Light L;
+        std::memset(&L, 0, sizeof L);
+        const H3 n = hnorm(c);
+        const double vv[3][3] = {{v[0].x, v[0].y, v[0].z}, {v[1].x, v[1].y, v[1].z}, {v[2].x, v[2].y, v[2].z}};
+        for (int a = 0; a < 3; ++a) { L.v0[a] = vv[0][a]; L.v1[a] = vv[1][a]; L.v2[a] = vv[2][a]; L.emission[a] = m.emission[a]; }
+        L.normal[0] = n.x; L.normal[1] = n.y; L.normal[2] = n.z;
+        L.cdf = acc;
+        L.leaf_index = leaf_of[g];
+        lights.push_back(L);
+    }
+    if ((rc = upload(s->d_lights, lights.data(), lights.size())) != PT_OK) return rc;
+
+    HIP_TRY(s->d_ctr.alloc(sizeof(ptd::Counters)));
+    HIP_TRY(hipMemset(s->d_ctr.p, 0, sizeof(ptd::Counters)));
+
+    ptd::Scene& dv = s->dev;
+    dv.nodes = s->d_nodes.as<float4>();
+    dv.tris = s->d_tris.as<float4>();
+    dv.uvs = d->tri_uvs ? s->d_uvs.as<float2>() : nullptr;
+    dv.leaf_of = s->d_leaf_of.as<uint32_t>();
+    dv.mats = s->d_mats.as<ptd::Material>();
+    dv.texs = s->d_texs.as<ptd::Texture>();
+    dv.lights = s->d_lights.as<ptd::Light>();
+    dv.n_nodes = d->n_tris ? (uint32_t)s->nodes.size() : 0u;
+    dv.n_tris = d->n_tris;
+    dv.n_lights = (uint32_t)lights.size();
+    dv.light_area = acc;
+    // scene.rs:38-42, hoisted out of Camera::ray
+    H3 view{d->camera.view[0], d->camera.view[1], d->camera.view[2]};
+    H3 up{d->camera.up[0], d->camera.up[1], d->camera.up[2]};
+    H3 a0 = hneg(hnorm(hcross(view, up)));
+    H3 a1 = hneg(hnorm(hcross(a0, view)));
+    double cc = d->camera.camera_const;
+    for (int a = 0; a < 3; ++a) dv.cam.eye[a] = d->camera.eye[a];
+    dv.cam.view_dir[0] = view.x * cc; dv.cam.view_dir[1] = view.y * cc; dv.cam.view_dir[2] = view.z * cc;
+    dv.cam.axes0[0] = a0.x; dv.cam.axes0[1] = a0.y; dv.cam.axes0[2] = a0.z;
+    dv.cam.axes1[0] = a1.x; dv.cam.axes1[1] = a1.y; dv.cam.axes1[2] = a1.z;
+    for (int a = 0; a < 3; ++a) dv.background[a] = d->background[a];
+
+    *out = s.release();
+    return PT_OK;
+}
+
+void pt_scene_destroy(pt_scene* scene) {
+    if (!scene) return;
+    DeviceGuard guard(scene->device);
+    (void)hipDeviceSynchronize();
+    delete scene;
+}
+
+int pt_scene_get_bvh(const pt_scene* s, const pt_bvh_node** nodes, uint32_t* n_nodes, const uint32_t** tri_order,
+                     uint32_t* max_depth) {
+    if (!s) { set_error("null scene"); return PT_ERR_INVALID; }
+    if (nodes) *nodes = s->nodes.data();
+    if (n_nodes) *n_nodes = (uint32_t)s->nodes.size();
+    if (tri_order) *tri_order = s->order.data();
+    if (max_depth) *max_depth = s->depth;
+    return PT_OK;
+}
+
+int pt_set_profiling(pt_scene* s, int level) {
+    if (!s || level < 0 || level > 2) { set_error("bad argument"); return PT_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->profiling = level;
+    return PT_OK;
+}
+
+int pt_reset_stats(pt_scene* s) {
+    if (!s) { set_error("null scene"); return PT_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(s->mu);
+    DeviceGuard guard(s->device);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(s->d_ctr.p, 0, sizeof(ptd::Counters)));
+    std::memset(&s->stats, 0, sizeof s->stats);
+    return PT_OK;
+}
+
+int pt_get_stats(pt_scene* s, pt_stats* out) {
+    if (!s || !out) { set_error("null argument"); return PT_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(s->mu);
+    DeviceGuard guard(s->device);
+    HIP_TRY(hipDeviceSynchronize());
+    ptd::Counters c;
+    HIP_TRY(hipMemcpy(&c, s->d_ctr.p, sizeof c, hipMemcpyDeviceToHost));
+    s->stats.rays = c.rays;
+    s->stats.shadow_rays = c.shadow_rays;
+    s->stats.nodes_visited = c.nodes;
+    s->stats.tris_tested = c.tris;
+    *out = s->stats;
+    return PT_OK;
+}
+
+int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, void* stream) {
+    if (!s || !accum_dev) { set_error("null argument"); return PT_ERR_INVALID; }
+    int rc = check_params(P);
+    if (rc != PT_OK) return rc;
+    if (P->sample_count == 0) return PT_OK;
+    std::lock_guard<std::mutex> lk(s->mu);
+    DeviceGuard guard(s->device);
+    if (!guard.ok) { set_error("hipSetDevice(%d) failed", s->device); return PT_ERR_DEVICE; }
+    hipStream_t st = (hipStream_t)stream;
+
+    const uint32_t tw = P->x1 - P->x0, th = P->y1 - P->y0;
+    const uint32_t npix = tw * th;
+    const bool nee = (P->flags & PT_FLAG_NEE) != 0 && s->dev.n_lights > 0;
+    // frames in flight per pass: ~16M paths fill the chip many times over and keep launches few
+    uint32_t spp = P->spp_per_batch;
+    if (spp == 0) spp = std::max<uint32_t>(1u, (1u << 24) / npix);
+    spp = std::min(spp, P->sample_count);
+    spp = std::min<uint32_t>(spp, std::max<uint32_t>(1u, (1u << 30) / npix));
+    const uint32_t slots = spp * npix;
+    if ((rc = ensure_workspace(s, slots, nee)) != PT_OK) return rc;
+    Workspace& w = s->ws;
+    if (w.jitter_cap < P->sample_count) {
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(w.jitter.alloc((size_t)P->sample_count * 2 * sizeof(double)));
+        w.jitter_cap = P->sample_count;
+    }
+    // main.rs:402-405: one jitter pair per frame, scaled by the pixel size
+    ptd::launch_jitter(P->seed, P->sample_begin, P->sample_count, 1. / (double)P->width, 1. / (double)P->height,
+                       w.jitter.as<double>(), st);
+    const bool stats = s->profiling >= 2;
+    ptd::Counters* ctr = s->d_ctr.as<ptd::Counters>();
+
+    for (uint32_t b0 = 0; b0 < P->sample_count; b0 += spp) {
+        const uint32_t ns = std::min(spp, P->sample_count - b0);
+        ptd::Frame fr;
+        fr.width = P->width; fr.height = P->height;
+        fr.x0 = P->x0; fr.y0 = P->y0; fr.tile_w = tw; fr.tile_h = th;
+        fr.n_tile_pixels = npix;
+        fr.n_samples = ns;
+        fr.sample_base = P->sample_begin + b0;
+        fr.seed = P->seed;
+        fr.max_bounces = P->max_bounces;
+        fr.flags = P->flags;
+        fr.jitter = w.jitter.as<double>() + (size_t)b0 * 2;
+        const uint32_t n_max = ns * npix;
+        HIP_TRY(hipMemsetAsync(w.counters, 0, kCounterWords * sizeof(uint32_t), st));
+        {
+            Timer t(s, st, PT_K_GENERATE);
+            ptd::launch_generate(s->dev, fr, w.q[0], st);
+        }
+        for (uint32_t bounce = 0; bounce <= P->max_bounces; ++bounce) {
+            const uint32_t* cnt = bounce == 0 ? nullptr : w.counters + bounce;
+            ptd::Queue& qin = w.q[bounce & 1];
+            ptd::Queue& qout = w.q[(bounce + 1) & 1];
+            {
+                Timer t(s, st, PT_K_EXTEND);
+                ptd::launch_extend(s->dev, qin, nullptr, nullptr, cnt, n_max, w.hits, ctr, stats, st);
+            }
+            {
+                Timer t(s, st, PT_K_SHADE);
+                ptd::launch_shade(s->dev, fr, bounce, qin, w.hits, cnt, n_max, qout, w.counters + bounce + 1, w.sq,
+                                  w.counters + 64 + bounce, w.ls, st);
+            }
+            if (nee && bounce < P->max_bounces) {
+                Timer t(s, st, PT_K_SHADOW);
+                ptd::launch_shadow(s->dev, w.sq, w.counters + 64 + bounce, n_max, w.ls, ctr, st);
+            }
+        }
+        {
+            Timer t(s, st, PT_K_ACCUMULATE);
+            ptd::launch_accumulate(fr, w.ls, accum_dev, st);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    s->stats.samples += (uint64_t)npix * P->sample_count;
+    if (s->profiling >= 1) return collect_timers(s, st);
+    return PT_OK;
+}
+
+int pt_render(pt_scene* s, const pt_render_params* P, double* accum_rgb) {
+    if (!s || !accum_rgb) { set_error("null argument"); return PT_ERR_INVALID; }
+    int rc = check_params(P);
+    if (rc != PT_OK) return rc;
+    DeviceGuard guard(s->device);
+    if (!guard.ok) { set_error("hipSetDevice(%d) failed", s->device); return PT_ERR_DEVICE; }
+    size_t n = (size_t)P->width * P->height * 3;
+    DevBuf acc;
+    hipError_t e = acc.alloc(n * sizeof(double));
+    if (e != hipSuccess) { set_error("accumulation buffer allocation failed: %s", hipGetErrorString(e)); return PT_ERR_NOMEM; }
+    HIP_TRY(hipMemcpy(acc.p, accum_rgb, n * sizeof(double), hipMemcpyHostToDevice));
+    rc = pt_render_device(s, P, acc.as<double>(), nullptr);
+    if (rc != PT_OK) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(accum_rgb, acc.p, n * sizeof(double), hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_trace_closest(pt_scene* s, const pt_ray* rays, size_t n, uint32_t* tri_id, double* t) {
+    if (!s || (n && (!rays || !tri_id || !t))) { set_error("null argument"); return PT_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(s->mu);
+    DeviceGuard guard(s->device);
+    if (!guard.ok) { set_error("hipSetDevice(%d) failed", s->device); return PT_ERR_DEVICE; }
+    const size_t chunk = 1u << 22;
+    DevBuf buf;
+    std::vector<double> host;
+    for (size_t c0 = 0; c0 < n; c0 += chunk) {
+        uint32_t m = (uint32_t)std::min(chunk, n - c0);
+        // SoA staging: ox oy oz dx dy dz tmin tmax | t_out | tri_out
+        host.resize((size_t)m * 8);
+        for (uint32_t i = 0; i < m; ++i) {
+            const pt_ray& r = rays[c0 + i];
+            for (int a = 0; a < 3; ++a) { host[(size_t)a * m + i] = r.o[a]; host[(size_t)(3 + a) * m + i] = r.d[a]; }
+            host[(size_t)6 * m + i] = r.t_min;
+            host[(size_t)7 * m + i] = r.t_max;
+        }
+        HIP_TRY(buf.alloc((size_t)m * (9 * sizeof(double) + sizeof(uint32_t))));
+        double* db = buf.as<double>();
+        HIP_TRY(hipMemcpy(db, host.data(), (size_t)m * 8 * sizeof(double), hipMemcpyHostToDevice));
+        ptd::Queue q;
+        std::memset(&q, 0, sizeof q);
+        for (int a = 0; a < 3; ++a) { q.o[a] = db + (size_t)a * m; q.d[a] = db + (size_t)(3 + a) * m; }
+        ptd::Hits hits;
+        hits.t = db + (size_t)8 * m;
+        hits.tri = (uint32_t*)(db + (size_t)9 * m);
+        {
+            Timer tm(s, nullptr, PT_K_EXTEND);
+            ptd::launch_extend(s->dev, q, db + (size_t)6 * m, db + (size_t)7 * m, nullptr, m, hits,
+                               s->d_ctr.as<ptd::Counters>(), s->profiling >= 2, nullptr);
+        }
+        ptd::launch_leaf_to_global(s->dev, hits.tri, m, nullptr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(t + c0, hits.t, (size_t)m * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(tri_id + c0, hits.tri, (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
+    if (s->profiling >= 1) return collect_timers(s, nullptr);
+    return PT_OK;
+}
+
+int pt_generate_rays(pt_scene* s, const pt_render_params* P, uint64_t sample, pt_ray* rays) {
+    if (!s || !rays) { set_error("null argument"); return PT_ERR_INVALID; }
+    int rc = check_params(P);
+    if (rc != PT_OK) return rc;
+    std::lock_guard<std::mutex> lk(s->mu);
+    DeviceGuard guard(s->device);
+    if (!guard.ok) { set_error("hipSetDevice(%d) failed", s->device); return PT_ERR_DEVICE; }
+    const uint32_t tw = P->x1 - P->x0, th = P->y1 - P->y0, npix = tw * th;
+    DevBuf out, jit;
+    HIP_TRY(out.alloc((size_t)npix * sizeof(pt_ray)));
+    HIP_TRY(jit.alloc(2 * sizeof(double)));
+    ptd::launch_jitter(P->seed, sample, 1, 1. / (double)P->width, 1. / (double)P->height, jit.as<double>(), nullptr);
+    ptd::Frame fr;
+    std::memset(&fr, 0, sizeof fr);
+    fr.width = P->width; fr.height = P->height; fr.x0 = P->x0; fr.y0 = P->y0; fr.tile_w = tw; fr.tile_h = th;
+    fr.n_tile_pixels = npix; fr.n_samples = 1; fr.sample_base = sample; fr.seed = P->seed;
+    fr.max_bounces = P->max_bounces; fr.flags = P->flags; fr.jitter = jit.as<double>();
+    ptd::launch_generate_rays(s->dev, fr, out.as<double>(), nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(rays, out.p, (size_t)npix * sizeof(pt_ray), hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_sample_brdf(pt_scene* s, const pt_ray* rays, const uint32_t* tri_id, const double* t, const uint32_t* pixel,
+                   size_t n, uint64_t sample, uint32_t bounce, uint64_t seed, uint32_t flags, uint32_t width,
+                   uint32_t height, double* f, double* wi, double* pdf, double* emission, double* position) {
+    if (!s || (n && (!rays || !tri_id || !t || !pixel || !f || !wi || !pdf || !emission || !position))) {
+        set_error("null argument");
+        return PT_ERR_INVALID;
+    }
+    if (width == 0 || height == 0 || n >= (1ull << 31)) { set_error("bad argument"); return PT_ERR_INVALID; }
+    for (size_t i = 0; i < n; ++i) {
+        if (tri_id[i] >= s->n_tris) { set_error("ray %zu: triangle id out of range", i); return PT_ERR_INVALID; }
+        if (pixel[i] >= (uint64_t)width * height) { set_error("ray %zu: pixel out of range", i); return PT_ERR_INVALID; }
+    }
+    if (n == 0) return PT_OK;
+    std::lock_guard<std::mutex> lk(s->mu);
+    DeviceGuard guard(s->device);
+    if (!guard.ok) { set_error("hipSetDevice(%d) failed", s->device); return PT_ERR_DEVICE; }
+    DevBuf d_rays, d_tri, d_t, d_pix, d_out, jit;
+    int rc;
+    if ((rc = upload(d_rays, rays, n)) != PT_OK) return rc;
+    if ((rc = upload(d_tri, tri_id, n)) != PT_OK) return rc;
+    if ((rc = upload(d_t, t, n)) != PT_OK) return rc;
+    if ((rc = upload(d_pix, pixel, n)) != PT_OK) return rc;
+    HIP_TRY(d_out.alloc(n * 13 * sizeof(double)));
+    HIP_TRY(jit.alloc(2 * sizeof(double)));
+    ptd::launch_jitter(seed, sample, 1, 1. / (double)width, 1. / (double)height, jit.as<double>(), nullptr);
+    ptd::Frame fr;
+    std::memset(&fr, 0, sizeof fr);
+    fr.width = width; fr.height = height; fr.tile_w = width; fr.tile_h = height; fr.n_tile_pixels = width * height;
+    fr.n_samples = 1; fr.sample_base = sample; fr.seed = seed; fr.flags = flags; fr.jitter = jit.as<double>();
+    double* o = d_out.as<double>();
+    ptd::launch_sample_brdf(s->dev, fr, bounce, d_rays.as<double>(), d_tri.as<uint32_t>(), d_t.as<double>(),
+                            d_pix.as<uint32_t>(), (uint32_t)n, o, o + 3 * n, o + 6 * n, o + 7 * n, o + 10 * n, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(f, o, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(wi, o + 3 * n, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pdf, o + 6 * n, n * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(emission, o + 7 * n, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(position, o + 10 * n, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_texture_lookup(pt_scene* s, uint32_t tex, const double* uv, const double* duvdx, const double* duvdy, size_t n,
+                      double* rgb) {
+    if (!s || (n && (!uv || !duvdx || !duvdy || !rgb))) { set_error("null argument"); return PT_ERR_INVALID; }
+    if (tex >= s->n_texs) { set_error("texture %u out of range", tex); return PT_ERR_INVALID; }
+    if (n == 0) return PT_OK;
+    if (n >= (1ull << 31)) { set_error("too many lookups"); return PT_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(s->mu);
+    DeviceGuard guard(s->device);
+    if (!guard.ok) { set_error("hipSetDevice(%d) failed", s->device); return PT_ERR_DEVICE; }
+    DevBuf d_uv, d_dx, d_dy, d_out;
+    int rc;
+    if ((rc = upload(d_uv, uv, 2 * n)) != PT_OK) return rc;
+    if ((rc = upload(d_dx, duvdx, 2 * n)) != PT_OK) return rc;
+    if ((rc = upload(d_dy, duvdy, 2 * n)) != PT_OK) return rc;
+    HIP_TRY(d_out.alloc(3 * n * sizeof(double)));
+    ptd::launch_texture_lookup(s->dev, tex, d_uv.as<double>(), d_dx.as<double>(), d_dy.as<double>(), (uint32_t)n,
+                               d_out.as<double>(), nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(rgb, d_out.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,289 @@
+// pt_bvh.cpp — host-side BVH build, the stand-in for `e_BVH::unanimated(8, ..)` (bvh.rs:17-21,
+// triangle_mesh.rs:44).  The reference's builder lives in an un-vendored crate, so
+// this is the build's own: binned SAH over triangle centroids, leaves of at most `max_leaf`
+// triangles, flattened into the two-child node format of include/pt.h.
+//
+// Two properties the extend kernel relies on:
+//  * depth bound: the tree never gets deeper than kMaxDepth, so the per-lane LDS stack of
+//    ptd::kStackDepth entries cannot overflow (when the SAH split would leave too little depth
+//    budget for the remaining triangles the builder switches to median splits);
+//  * conservative boxes: child boxes are stored as f32 and padded outward by ~2^-21 of the scene's
+//    largest coordinate, nine orders of magnitude more than the rounding error of the f64 slab
+//    test, so a box never culls a triangle that triangle_mesh.rs:101-126 would accept.
+#include "pt_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+namespace pth {
+
+namespace {
+
+struct Ref {
+    float lo[3], hi[3];
+    float c[3];
+    uint32_t id;
+};
+struct Box {
+    float lo[3], hi[3];
+    void reset() {
+        for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+    }
+    void grow(const float* l, const float* h) {
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], l[a]); hi[a] = std::max(hi[a], h[a]); }
+    }
+    void grow_pt(const float* p) {
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); }
+    }
+    float half_area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (!(dx >= 0.f)) return 0.f;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct TNode {  // temporary tree
+    Box box;
+    int left = -1, right = -1;
+    uint32_t first = 0, count = 0;
+};
+
+constexpr int kBins = 16;
+constexpr int kMaxDepth = 30;  // inner-node levels; stack needs <= depth entries (< ptd::kStackDepth = 32)
+
+struct Builder {
+    std::vector<Ref>& refs;
+    uint32_t max_leaf;
+    std::vector<TNode> nodes;
+    uint32_t max_depth = 0;
+
+    Builder(std::vector<Ref>& r, uint32_t ml) : refs(r), max_leaf(ml) {}
+
+    static int ceil_log2(uint32_t x) {
+        int l = 0;
+        while ((1u << l) < x) ++l;
+        return l;
+    }
+
+    int build(uint32_t first, uint32_t count, int depth) {
+        int idx = (int)nodes.size();
+        nodes.emplace_back();
+        Box box, cbox;
+        box.reset();
+        cbox.reset();
+        for (uint32_t i = first; i < first + count; ++i) {
+            box.grow(refs[i].lo, refs[i].hi);
+            cbox.grow_pt(refs[i].c);
+        }
+        nodes[idx].box = box;
+        nodes[idx].first = first;
+        nodes[idx].count = count;
+        max_depth = std::max(max_depth, (uint32_t)depth);
+        if (count <= max_leaf) return idx;
+
+        uint32_t mid = 0;
+        bool have_split = false;
+        // levels still needed if we split evenly from here on
+        int need = ceil_log2((count + max_leaf - 1) / max_leaf);
+        bool budget_ok = depth + need + 2 < kMaxDepth;
+        if (budget_ok) {
+            float best_cost = INFINITY;
+            int best_axis = -1, best_bin = -1;
+            for (int axis = 0; axis < 3; ++axis) {
+                float cmin = cbox.lo[axis], cmax = cbox.hi[axis];
+                if (!(cmax > cmin)) continue;
+                float scale = (float)kBins / (cmax - cmin);
+                Box bb[kBins];
+                uint32_t bc[kBins];
+                for (int b = 0; b < kBins; ++b) { bb[b].reset(); bc[b] = 0; }
+                for (uint32_t i = first; i < first + count; ++i) {
+                    int b = std::min(kBins - 1, (int)((refs[i].c[axis] - cmin) * scale));
+                    bb[b].grow(refs[i].lo, refs[i].hi);
+                    bc[b]++;
+                }
+                float right_area[kBins];
+                uint32_t right_cnt[kBins];
+                Box acc;
+                acc.reset();
+                uint32_t cnt = 0;
+                for (int b = kBins - 1; b > 0; --b) {
+                    acc.grow(bb[b].lo, bb[b].hi);
+                    cnt += bc[b];
+                    right_area[b] = acc.half_area();
+                    right_cnt[b] = cnt;
+                }
+                acc.reset();
+                cnt = 0;
+                for (int b = 0; b < kBins - 1; ++b) {
+                    acc.grow(bb[b].lo, bb[b].hi);
+                    cnt += bc[b];
+                    if (cnt == 0 || right_cnt[b + 1] == 0) continue;
+                    float cost = acc.half_area() * (float)cnt + right_area[b + 1] * (float)right_cnt[b + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+                }
+            }
+            if (best_axis >= 0) {
+                float cmin = cbox.lo[best_axis], cmax = cbox.hi[best_axis];
+                float scale = (float)kBins / (cmax - cmin);
+                auto it = std::partition(refs.begin() + first, refs.begin() + first + count, [&](const Ref& r) {
+                    int b = std::min(kBins - 1, (int)((r.c[best_axis] - cmin) * scale));
+                    return b <= best_bin;
+                });
+                mid = (uint32_t)(it - refs.begin());
+                have_split = mid > first && mid < first + count;
+            }
+        }
+        if (!have_split) {  // median split on the widest centroid axis (also the depth-budget fallback)
+            int axis = 0;
+            for (int a = 1; a < 3; ++a)
+                if (cbox.hi[a] - cbox.lo[a] > cbox.hi[axis] - cbox.lo[axis]) axis = a;
+            mid = first + count / 2;
+            std::nth_element(refs.begin() + first, refs.begin() + mid, refs.begin() + first + count,
+                             [&](const Ref& a, const Ref& b) { return a.c[axis] < b.c[axis] || (a.c[axis] == b.c[axis] && a.id < b.id); });
+        }
+        int l = build(first, mid - first, depth + 1);
+        int r = build(mid, first + count - mid, depth + 1);
+        nodes[idx].left = l;
+        nodes[idx].right = r;
+        return idx;
+    }
+};
+
+inline float round_down(double x) {
+    float f = (float)x;
+    if ((double)f > x) f = std::nextafterf(f, -INFINITY);
+    return f;
+}
+inline float round_up(double x) {
+    float f = (float)x;
+    if ((double)f < x) f = std::nextafterf(f, INFINITY);
+    return f;
+}
+
+}  // namespace
+
+int bvh_build(const float* verts, uint32_t n_verts, const uint32_t* tris, uint32_t n_tris, uint32_t max_leaf,
+              std::vector<pt_bvh_node>& out_nodes, std::vector<uint32_t>& out_order, uint32_t& out_depth) {
+    if (max_leaf < 1 || max_leaf > 8) return PT_ERR_INVALID;
+    if (n_tris >= (1u << 28)) return PT_ERR_UNSUPPORTED;  // leaf code keeps `first` in 28 bits
+    out_nodes.clear();
+    out_order.clear();
+    out_depth = 0;
+    if (n_tris == 0) return PT_OK;
+    std::vector<Ref> refs(n_tris);
+    double max_abs = 0.;
+    for (uint32_t i = 0; i < n_tris; ++i) {
+        Ref& r = refs[i];
+        for (int a = 0; a < 3; ++a) { r.lo[a] = INFINITY; r.hi[a] = -INFINITY; }
+        for (int k = 0; k < 3; ++k) {
+            uint32_t v = tris[3 * i + k];
+            if (v >= n_verts) return PT_ERR_INVALID;
+            for (int a = 0; a < 3; ++a) {
+                float x = verts[3 * v + a];
+                if (!std::isfinite(x)) return PT_ERR_INVALID;
+                r.lo[a] = std::min(r.lo[a], x);
+                r.hi[a] = std::max(r.hi[a], x);
+                max_abs = std::max(max_abs, (double)std::fabs(x));
+            }
+        }
+        for (int a = 0; a < 3; ++a) r.c[a] = 0.5f * r.lo[a] + 0.5f * r.hi[a];
+        r.id = i;
+    }
+    Builder b(refs, max_leaf);
+    b.nodes.reserve((size_t)n_tris * 2 / max_leaf + 16);
+    b.build(0, n_tris, 0);
+
+    out_order.resize(n_tris);
+    for (uint32_t i = 0; i < n_tris; ++i) out_order[i] = refs[i].id;
+
+    const double pad = std::max(max_abs, 1e-30) * (1.0 / 2097152.0);  // 2^-21 of the largest |coordinate|
+    auto leaf_code = [](const TNode& n) { return ~(int32_t)((n.first << 3) | (n.count - 1)); };
+    auto put_box = [&](pt_bvh_node& dst, int child, const Box& bx) {
+        for (int a = 0; a < 3; ++a) {
+            dst.bounds[child * 6 + a] = round_down((double)bx.lo[a] - pad);
+            dst.bounds[child * 6 + 3 + a] = round_up((double)bx.hi[a] + pad);
+        }
+    };
+    // flatten: inner temp nodes get consecutive output indices in depth-first order
+    std::vector<int> out_index(b.nodes.size(), -1);
+    uint32_t n_inner = 0;
+    for (size_t i = 0; i < b.nodes.size(); ++i)
+        if (b.nodes[i].left >= 0) out_index[i] = (int)n_inner++;
+    if (n_inner == 0) {  // the root is a leaf: one node with a single child
+        pt_bvh_node node;
+        std::memset(&node, 0, sizeof node);
+        put_box(node, 0, b.nodes[0].box);
+        node.child[0] = leaf_code(b.nodes[0]);
+        for (int a = 0; a < 6; ++a) node.bounds[6 + a] = 0.f;
+        node.child[1] = PT_BVH_EMPTY;
+        out_nodes.push_back(node);
+        out_depth = 1;
+        return PT_OK;
+    }
+    out_nodes.resize(n_inner);
+    for (size_t i = 0; i < b.nodes.size(); ++i) {
+        const TNode& n = b.nodes[i];
+        if (n.left < 0) continue;
+        pt_bvh_node node;
+        std::memset(&node, 0, sizeof node);
+        const TNode& l = b.nodes[n.left];
+        const TNode& r = b.nodes[n.right];
+        put_box(node, 0, l.box);
+        put_box(node, 1, r.box);
+        node.child[0] = l.left >= 0 ? out_index[n.left] : leaf_code(l);
+        node.child[1] = r.left >= 0 ? out_index[n.right] : leaf_code(r);
+        out_nodes[out_index[i]] = node;
+    }
+    out_depth = b.max_depth;
+    return PT_OK;
+}
+
+// Walks a BVH (the library's or a caller's) and checks everything the extend kernel assumes:
+// child indices in range, no cycles (each inner node reached once), leaf runs inside
+// [0, n_tris), every triangle referenced exactly once, depth within the LDS stack.
+int bvh_validate(const pt_bvh_node* nodes, uint32_t n_nodes, const uint32_t* order, uint32_t n_tris,
+                 uint32_t stack_depth, uint32_t& depth_out, std::string& why) {
+    depth_out = 0;
+    if (n_tris == 0) return PT_OK;
+    if (n_nodes == 0) { why = "BVH has no nodes"; return PT_ERR_INVALID; }
+    std::vector<uint8_t> seen_node(n_nodes, 0), seen_tri(n_tris, 0);
+    for (uint32_t i = 0; i < n_tris; ++i) {
+        if (order[i] >= n_tris) { why = "bvh_tri_order entry out of range"; return PT_ERR_INVALID; }
+    }
+    struct Item { int node; uint32_t depth; };
+    std::vector<Item> st;
+    st.push_back({0, 1});
+    seen_node[0] = 1;
+    uint64_t covered = 0;
+    while (!st.empty()) {
+        Item it = st.back();
+        st.pop_back();
+        depth_out = std::max(depth_out, it.depth);
+        if (it.depth > stack_depth) { why = "BVH deeper than the traversal stack"; return PT_ERR_UNSUPPORTED; }
+        for (int c = 0; c < 2; ++c) {
+            int32_t ch = nodes[it.node].child[c];
+            if (ch == PT_BVH_EMPTY) continue;
+            if (ch >= 0) {
+                if ((uint32_t)ch >= n_nodes) { why = "BVH child index out of range"; return PT_ERR_INVALID; }
+                if (seen_node[ch]) { why = "BVH node referenced twice"; return PT_ERR_INVALID; }
+                seen_node[ch] = 1;
+                st.push_back({ch, it.depth + 1});
+            } else {
+                uint32_t code = (uint32_t)~ch;
+                uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
+                if ((uint64_t)first + cnt > n_tris) { why = "BVH leaf run out of range"; return PT_ERR_INVALID; }
+                for (uint32_t k = first; k < first + cnt; ++k) {
+                    if (seen_tri[k]) { why = "triangle slot in two leaves"; return PT_ERR_INVALID; }
+                    seen_tri[k] = 1;
+                }
+                covered += cnt;
+            }
+        }
+    }
+    if (covered != n_tris) { why = "BVH leaves do not cover every triangle"; return PT_ERR_INVALID; }
+    return PT_OK;
+}
+
+}  // namespace pth

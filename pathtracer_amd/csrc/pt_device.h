@@ -1,0 +1,127 @@
+// pt_device.h — device-side data layout and launcher declarations of the gfx950 wavefront path
+// tracer.  Host code (pt_api.cpp) fills these structs; pt_kernels.hip consumes them.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ptd {
+
+// ---- scene in HBM -------------------------------------------------------------------------
+// nodes : 4 x float4 per pt_bvh_node  (64 B, one node = both children's boxes + child refs)
+// tris  : 3 x float4 per triangle, in BVH leaf order:
+//           [0] = v0.xyz , bits(global triangle id)
+//           [1] = v1.xyz , bits(material id)
+//           [2] = v2.xyz , 0
+//         f32 vertices are what tobj delivers (obj.rs:25); widening to f64 in the kernel is exact.
+// uvs   : 3 x float2 per triangle (leaf order) or nullptr = (0,0),(1,0),(1,1) (triangle_mesh.rs:93)
+struct Material {
+    double color[3];
+    double emission[3];
+    double width;  // Beckmann width = max(roughness, 1e-5) (microfacet.rs:125)
+    int32_t kind;
+    int32_t tex;
+};
+
+struct Texture {
+    const double* texels;  // all levels, 3 doubles per texel, level l starts at offset[l] texels
+    uint32_t n_levels;
+    uint32_t width0, height0;
+    uint32_t offset[16];
+};
+
+struct Camera {  // scene.rs:37-43 with the per-ray invariant parts hoisted to the host
+    double eye[3];
+    double view_dir[3];  // view_direction * camera_const
+    double axes0[3];     // -(view x up).normalize()
+    double axes1[3];     // -(axes0 x view).normalize()
+};
+
+struct Light {  // one emissive triangle (NEE)
+    double v0[3], v1[3], v2[3];
+    double normal[3];  // unit geometric normal
+    double emission[3];
+    double cdf;        // cumulative area up to and including this triangle
+    uint32_t leaf_index;  // index of the triangle in leaf order
+    uint32_t pad;
+};
+
+struct Scene {
+    const float4* nodes;
+    const float4* tris;
+    const float2* uvs;
+    const uint32_t* leaf_of;  // global triangle id -> leaf-order index
+    const Material* mats;
+    const Texture* texs;
+    const Light* lights;
+    uint32_t n_nodes, n_tris, n_lights, pad;
+    double light_area;
+    Camera cam;
+    double background[3];
+};
+
+// ---- ray / path queue (SoA, one entry per path in flight) -----------------------------------
+struct Queue {
+    double* o[3];
+    double* d[3];
+    double* T[3];      // path throughput ("accumulated_pdf", main.rs:290)
+    double* prev_pdf;  // pdf of the BRDF sample that spawned the ray (NEE/MIS only)
+    uint32_t* slot;    // path slot = sample_in_batch * n_tile_pixels + tile_pixel
+};
+
+struct Sample3 {  // per-slot radiance of the batch ("color_result", main.rs:287), SoA
+    double* c[3];
+};
+
+struct Hits {
+    uint32_t* tri;  // leaf-order triangle index or PT_MISS
+    double* t;
+};
+
+struct ShadowQueue {
+    double* o[3];
+    double* d[3];
+    double* tmax;
+    double* c[3];  // contribution added to the sample if unoccluded
+    uint32_t* slot;
+};
+
+struct Frame {  // per-call constants of generate / shade
+    uint32_t width, height;
+    uint32_t x0, y0, tile_w, tile_h;
+    uint32_t n_tile_pixels;
+    uint32_t n_samples;    // frames in this batch
+    uint64_t sample_base;  // frame index of sample 0 of the batch
+    uint64_t seed;
+    uint32_t max_bounces;
+    uint32_t flags;
+    const double* jitter;  // [n_samples][2] frame jitters, already scaled by the pixel size
+};
+
+struct Counters {  // device-side statistics (pt_stats)
+    unsigned long long rays, shadow_rays, nodes, tris;
+};
+
+constexpr int kStackDepth = 32;  // LDS traversal stack entries per lane; builder bounds tree depth
+constexpr int kBlock = 256;
+
+// ---- launchers (pt_kernels.hip) ---------------------------------------------------------------
+void launch_generate(const Scene& sc, const Frame& fr, Queue q, hipStream_t st);
+void launch_generate_rays(const Scene& sc, const Frame& fr, double* rays_out /* pt_ray[n] */, hipStream_t st);
+// count == nullptr -> n_max rays are live
+void launch_extend(const Scene& sc, Queue q, const double* tmin, const double* tmax, const uint32_t* count,
+                   uint32_t n_max, Hits hits, Counters* ctr, bool stats, hipStream_t st);
+void launch_shade(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, Hits hits, const uint32_t* count,
+                  uint32_t n_max, Queue out, uint32_t* out_count, ShadowQueue sq, uint32_t* sq_count,
+                  Sample3 lsample, hipStream_t st);
+void launch_shadow(const Scene& sc, ShadowQueue sq, const uint32_t* count, uint32_t n_max, Sample3 lsample,
+                   Counters* ctr, hipStream_t st);
+void launch_accumulate(const Frame& fr, Sample3 lsample, double* accum, hipStream_t st);
+// parity entry points
+void launch_leaf_to_global(const Scene& sc, uint32_t* tri, uint32_t n, hipStream_t st);
+void launch_sample_brdf(const Scene& sc, const Frame& fr, uint32_t bounce, const double* rays /* pt_ray[n] */,
+                        const uint32_t* tri_leaf, const double* t, const uint32_t* pixel, uint32_t n, double* f,
+                        double* wi, double* pdf, double* emission, double* position, hipStream_t st);
+void launch_texture_lookup(const Scene& sc, uint32_t tex, const double* uv, const double* duvdx,
+                           const double* duvdy, uint32_t n, double* rgb, hipStream_t st);
+
+}  // namespace ptd

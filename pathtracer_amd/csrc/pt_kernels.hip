@@ -1,0 +1,826 @@
+// pt_kernels.hip — gfx950 (CDNA4, wave64) wavefront path-tracing kernels.
+//
+//   generate   main.rs:409-427 pixel mapping + scene.rs:37-57 Camera::ray          -> ray queue
+//   extend     scene.rs:61 trace_closest: BVH traversal with an LDS-resident per-lane stack and
+//              the f64 ray/triangle test of triangle_mesh.rs:101-126                  -> hit records
+//   shade      main.rs:303-314: emission, _Material::sample_brdf (material.rs:37-58,
+//              microfacet.rs:52-93), mip-mapped texture lookup (mipmap.rs:100-141), throughput
+//              update, next ray; survivors are compacted with wave64 ballot + mbcnt prefix sums
+//   shadow     any-hit visibility for next-event estimation (lights.rs:51-60 shadow ray)
+//   accumulate main.rs:434-436 pixels[i] += next[i], frames added in index order
+//
+// Everything is f64 like the reference (vec3.rs:6) and this file is compiled with
+// -ffp-contract=off: the reference never fuses a*b+c, and primary-ray hit ids / distances have
+// to be bit-identical to the CPU restatement.  Vertices and boxes are f32 in memory (the
+// reference's own storage precision at those points: obj.rs:25, bvh.rs:98-101).
+#include "pt_device.h"
+
+#include "../../include/pt.h"
+
+namespace ptd {
+
+// ------------------------------------------------------------------------------------------------
+// f64 vector helpers — operation order follows algebra/vec3.rs
+struct D3 {
+    double x, y, z;
+};
+__device__ __forceinline__ D3 mk(double x, double y, double z) { return D3{x, y, z}; }
+__device__ __forceinline__ D3 ld3(const double* p) { return D3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ D3 operator-(D3 a, D3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ D3 operator-(D3 a) { return {-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ D3 operator+(D3 a, D3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ D3 operator*(D3 a, D3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ D3 operator*(D3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ D3 operator*(double s, D3 a) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ D3 operator/(D3 a, double s) { return {a.x / s, a.y / s, a.z / s}; }
+__device__ __forceinline__ double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ D3 cross(D3 a, D3 b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ double length(D3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+__device__ __forceinline__ D3 normalize(D3 a) { return a / length(a); }  // vec3.rs:110-112: division, not rsqrt
+__device__ __forceinline__ double comp(D3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+// vec3.rs:138-140 (normalises)
+__device__ __forceinline__ D3 reflect(D3 self, D3 other) { return normalize(self - 2. * dot(self, other) * other); }
+// vec3.rs:154-166
+__device__ __forceinline__ D3 rotate_to(D3 self, D3 n) {
+    double sign = (n.z != n.z) ? n.z : copysign(1.0, n.z);  // f64::signum
+    double a = -1. / (1. + fabs(n.z));
+    double b = n.x * n.y * a;
+    return mk(1. + n.x * n.x * a, b, -sign * n.x) * self.x + mk(sign * b, sign * (1. + n.y * n.y * a), -n.y) * self.y +
+           n * self.z;
+}
+
+#define PT_PI 3.14159265358979323846264338327950288
+#define PT_FRAC_1_PI 0.318309886183790671537767526745028724
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10, counter = (pixel, sample_lo, sample_hi, bounce | stream << 24), key = seed.
+enum { STREAM_BRDF = 0, STREAM_LIGHT = 1, STREAM_JITTER = 2 };
+__host__ __device__ __forceinline__ void uniform2(uint64_t seed, uint32_t pixel, uint64_t sample, uint32_t bounce,
+                                                  uint32_t stream, double& u0, double& u1) {
+    uint32_t c0 = pixel, c1 = (uint32_t)sample, c2 = (uint32_t)(sample >> 32), c3 = bounce | (stream << 24);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;  // v_mul_hi_u32 + v_mul_lo_u32
+        uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0;
+        uint32_t h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
+        uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    uint64_t a = ((uint64_t)c1 << 32) | c0;
+    uint64_t b = ((uint64_t)c3 << 32) | c2;
+    u0 = (double)(a >> 11) * (1.0 / 9007199254740992.0);
+    u1 = (double)(b >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// main.rs:412-424 pixel -> arguments of render(); scene.rs:37-57 Camera::ray
+struct PixelArgs {
+    double x, y, ddx, ddy;
+};
+__device__ __forceinline__ PixelArgs pixel_args(uint32_t px, uint32_t py, uint32_t w, uint32_t h, double dx, double dy) {
+    double aspect = (double)w / (double)h;  // 1.0 for the reference's square images (F7)
+    double pixel_size_x = 1. / (double)w, pixel_size_y = 1. / (double)h;
+    double pixel_ndc_x = ((double)px + 0.5) / (double)w;
+    double pixel_ndc_y = ((double)py + 0.5) / (double)h;
+    double pixel_ss_x = 2. * pixel_ndc_x - 1.;
+    double pixel_ss_y = 1. - 2. * pixel_ndc_y;
+    return {(pixel_ss_x + dx) * aspect, pixel_ss_y + dy, 2. * pixel_size_x * aspect, 2. * pixel_size_y};
+}
+__device__ __forceinline__ D3 camera_dir(const Camera& c, double x, double y) {
+    return normalize(ld3(c.view_dir) + ld3(c.axes0) * x + ld3(c.axes1) * y);
+}
+
+// ------------------------------------------------------------------------------------------------
+// triangle_mesh.rs:101-126.  The conditions are evaluated in a different order than the reference
+// (barycentrics before the distance, so most candidates cost one division instead of two); every
+// condition is computed with the reference's arithmetic and they have no side effects, so the
+// accept/reject decision and the accepted t are identical.
+struct TriV {
+    D3 v0, v1, v2;
+};
+__device__ __forceinline__ TriV widen(float4 a, float4 b, float4 c) {
+    return {mk((double)a.x, (double)a.y, (double)a.z), mk((double)b.x, (double)b.y, (double)b.z),
+            mk((double)c.x, (double)c.y, (double)c.z)};
+}
+__device__ __forceinline__ bool tri_test(const TriV& tr, D3 o, D3 d, double t_min, double t_max, double& t_out,
+                                         double& v_out, double& w_out) {
+    D3 e0 = tr.v1 - tr.v0;
+    D3 e1 = tr.v0 - tr.v2;
+    D3 normal = cross(e0, e1);
+    double dn = dot(d, normal);
+    if (fabs(dn) < 1.0e-12) return false;
+    D3 vo = tr.v0 - o;
+    D3 tmp = cross(vo, d);
+    double denom = 1. / dn;
+    double v = dot(tmp, e1) * denom;
+    double w = dot(tmp, e0) * denom;
+    if (v < 0.0 || w < 0.0 || v + w > 1.0) return false;
+    double t = dot(vo, normal) / dn;
+    if (t < t_min || t > t_max) return false;
+    t_out = t; v_out = v; w_out = w;
+    return true;
+}
+
+// f64 slab test against an f32 box that the builder padded outward.  v_min/v_max_f64 return the
+// non-NaN operand, so a 0*inf (origin on a padded plane, parallel ray) yields a miss, which is
+// right: the padded plane holds no triangle of the box.
+__device__ __forceinline__ bool slab(double lox, double loy, double loz, double hix, double hiy, double hiz, D3 o,
+                                     D3 inv, double t_min, double t_max, double& t_near) {
+    double ax = (lox - o.x) * inv.x, bx = (hix - o.x) * inv.x;
+    double ay = (loy - o.y) * inv.y, by = (hiy - o.y) * inv.y;
+    double az = (loz - o.z) * inv.z, bz = (hiz - o.z) * inv.z;
+    double tn = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmax(fmin(az, bz), t_min));
+    double tf = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmin(fmax(az, bz), t_max));
+    t_near = tn;
+    return tn <= tf;
+}
+
+// BVH traversal, one ray per lane, stack in LDS laid out [entry][lane] (bank = lane: conflict-free).
+// ANY = stop at the first accepted triangle (shadow rays).  Returns leaf-order index / PT_MISS.
+template <bool ANY, bool STATS>
+__device__ __forceinline__ uint32_t traverse(const Scene& sc, D3 o, D3 d, double t_min, double& t_max, int* stk,
+                                             uint32_t& n_nodes, uint32_t& n_tris) {
+    uint32_t best = PT_MISS, best_id = PT_MISS;
+    if (sc.n_nodes == 0) return best;
+    D3 inv = mk(1. / d.x, 1. / d.y, 1. / d.z);
+    int sp = 0;
+    int cur = 0;
+    for (;;) {
+        if (cur >= 0) {
+            const float4* np = sc.nodes + (size_t)cur * 4;
+            float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+            int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+            double tn0, tn1;
+            bool h0 = slab((double)n0.x, (double)n0.y, (double)n0.z, (double)n0.w, (double)n1.x, (double)n1.y, o, inv,
+                           t_min, t_max, tn0) && c0 != PT_BVH_EMPTY;
+            bool h1 = slab((double)n1.z, (double)n1.w, (double)n2.x, (double)n2.y, (double)n2.z, (double)n2.w, o, inv,
+                           t_min, t_max, tn1) && c1 != PT_BVH_EMPTY;
+            if (STATS) n_nodes += 2;
+            if (h0 && h1) {
+                int nearc = c0, farc = c1;
+                if (tn1 < tn0) { nearc = c1; farc = c0; }
+                if (sp < kStackDepth) { stk[sp * kBlock] = farc; ++sp; }
+                cur = nearc;
+                continue;
+            } else if (h0) {
+                cur = c0;
+                continue;
+            } else if (h1) {
+                cur = c1;
+                continue;
+            }
+        } else {
+            int code = ~cur;
+            uint32_t first = (uint32_t)code >> 3, cnt = ((uint32_t)code & 7u) + 1u;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const float4* tp = sc.tris + (size_t)(first + k) * 3;
+                float4 a = tp[0], b = tp[1], c = tp[2];
+                TriV tr = widen(a, b, c);
+                if (STATS) n_tris += 1;
+                double t, v, w;
+                if (!tri_test(tr, o, d, t_min, t_max, t, v, w)) continue;
+                uint32_t gid = (uint32_t)__float_as_int(a.w);
+                // the reference accepts t == t_max (triangle_mesh.rs:113) and keeps the candidate
+                // tested last; the build-defined rule keeps the lowest triangle id
+                if (best != PT_MISS && !(t < t_max || gid < best_id)) continue;
+                best = first + k; best_id = gid; t_max = t;
+                if (ANY) return best;
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        cur = stk[sp * kBlock];
+    }
+    return best;
+}
+
+// XCD-aware block remap: hardware deals consecutive workgroups round-robin over the 8 XCDs, so
+// blocks b and b+8 share an L2.  Give every XCD one contiguous eighth of the queue (for primary
+// rays: a contiguous band of the image) so each L2 caches its own part of the scene.
+__device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t nb) {
+    uint32_t q = nb >> 3, r = nb & 7u, x = b & 7u, k = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_extend(Scene sc, Queue q, const double* __restrict__ tmin,
+                                                   const double* __restrict__ tmax,
+                                                   const uint32_t* __restrict__ count, uint32_t n_max, Hits hits,
+                                                   Counters* ctr) {
+    __shared__ int stack[kStackDepth * kBlock];
+    uint32_t n = count ? min(*count, n_max) : n_max;
+    uint32_t blk = xcd_block(blockIdx.x, gridDim.x);
+    uint32_t i = blk * kBlock + threadIdx.x;
+    if (ctr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->rays, (unsigned long long)n);
+    if (i >= n) return;
+    D3 o = mk(q.o[0][i], q.o[1][i], q.o[2][i]);
+    D3 d = mk(q.d[0][i], q.d[1][i], q.d[2][i]);
+    double t_min = tmin ? tmin[i] : 1e-5;                     // ray.rs:21
+    double t_max = tmax ? tmax[i] : 1.7976931348623157e308;   // ray.rs:22 f64::MAX
+    uint32_t nn = 0, nt = 0;
+    uint32_t tri = traverse<false, STATS>(sc, o, d, t_min, t_max, stack + threadIdx.x, nn, nt);
+    hits.tri[i] = tri;
+    hits.t[i] = t_max;
+    if (STATS) {
+        // wave-level reduction, one atomic pair per wave
+        for (int off = 32; off > 0; off >>= 1) {
+            nn += __shfl_down(nn, off);
+            nt += __shfl_down(nt, off);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&ctr->nodes, (unsigned long long)nn);
+            atomicAdd(&ctr->tris, (unsigned long long)nt);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_shadow(Scene sc, ShadowQueue sq, const uint32_t* __restrict__ count,
+                                                   uint32_t n_max, Sample3 ls, Counters* ctr) {
+    __shared__ int stack[kStackDepth * kBlock];
+    uint32_t n = min(*count, n_max);
+    uint32_t i = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
+    if (ctr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->shadow_rays, (unsigned long long)n);
+    if (i >= n) return;
+    D3 o = mk(sq.o[0][i], sq.o[1][i], sq.o[2][i]);
+    D3 d = mk(sq.d[0][i], sq.d[1][i], sq.d[2][i]);
+    double t_max = sq.tmax[i];
+    uint32_t nn = 0, nt = 0;
+    uint32_t tri = traverse<true, false>(sc, o, d, 1e-5, t_max, stack + threadIdx.x, nn, nt);
+    if (tri == PT_MISS) {
+        uint32_t slot = sq.slot[i];
+        ls.c[0][slot] += sq.c[0][i];
+        ls.c[1][slot] += sq.c[1][i];
+        ls.c[2][slot] += sq.c[2][i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// generate
+__global__ __launch_bounds__(kBlock) void k_generate(Scene sc, Frame fr, Queue q) {
+    uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t n = fr.n_tile_pixels * fr.n_samples;
+    if (slot >= n) return;
+    uint32_t s = slot / fr.n_tile_pixels, p = slot - s * fr.n_tile_pixels;
+    uint32_t ty = p / fr.tile_w, tx = p - ty * fr.tile_w;
+    PixelArgs a = pixel_args(fr.x0 + tx, fr.y0 + ty, fr.width, fr.height, fr.jitter[2 * s], fr.jitter[2 * s + 1]);
+    D3 dir = camera_dir(sc.cam, a.x, a.y);
+    q.o[0][slot] = sc.cam.eye[0]; q.o[1][slot] = sc.cam.eye[1]; q.o[2][slot] = sc.cam.eye[2];
+    q.d[0][slot] = dir.x; q.d[1][slot] = dir.y; q.d[2][slot] = dir.z;
+}
+
+// parity entry: the same rays as AoS pt_ray records (frame fr.sample_base, n_samples == 1)
+__global__ __launch_bounds__(kBlock) void k_generate_rays(Scene sc, Frame fr, double* __restrict__ rays) {
+    uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= fr.n_tile_pixels) return;
+    uint32_t ty = p / fr.tile_w, tx = p - ty * fr.tile_w;
+    PixelArgs a = pixel_args(fr.x0 + tx, fr.y0 + ty, fr.width, fr.height, fr.jitter[0], fr.jitter[1]);
+    D3 dir = camera_dir(sc.cam, a.x, a.y);
+    double* r = rays + (size_t)p * 8;
+    r[0] = sc.cam.eye[0]; r[1] = sc.cam.eye[1]; r[2] = sc.cam.eye[2];
+    r[3] = dir.x; r[4] = dir.y; r[5] = dir.z;
+    r[6] = 1e-5;
+    r[7] = 1.7976931348623157e308;
+}
+
+// ------------------------------------------------------------------------------------------------
+// mipmap.rs — texture lookup.  Texels are f64 RGB built on the host with the reference's
+// arithmetic (u8/255, 2x2 means), rows stored in the reference's `data` order.
+__device__ __forceinline__ uint32_t f64_as_usize_sat(double x) {  // Rust `as usize` (saturating, NaN -> 0)
+    if (!(x > 0.)) return 0u;
+    if (x >= 4294967295.0) return 0xFFFFFFFFu;  // any value past the clamp in get_pixel behaves alike
+    return (uint32_t)x;
+}
+__device__ __forceinline__ D3 get_pixel(const Texture& tx, uint32_t level, uint32_t w, uint32_t h, uint32_t s,
+                                        uint32_t t) {
+    uint32_t tt = min(t, h - 1), ss = min(s, w - 1);                  // mipmap.rs:44-46
+    const double* p = tx.texels + ((size_t)tx.offset[level] + (size_t)(h - tt - 1) * w + ss) * 3;  // mipmap.rs:52-55
+    return mk(p[0], p[1], p[2]);
+}
+__device__ __forceinline__ uint32_t sat_inc(uint32_t a) { return a == 0xFFFFFFFFu ? a : a + 1u; }
+__device__ D3 tex_triangle(const Texture& tx, uint32_t level, double u, double v) {  // mipmap.rs:100-115
+    uint32_t w = max(tx.width0 >> level, 1u), h = max(tx.height0 >> level, 1u);
+    double s = u * (double)w - 0.5;
+    double t = v * (double)h - 0.5;
+    uint32_t s0 = f64_as_usize_sat(s), t0 = f64_as_usize_sat(t);
+    double ds = s - (double)s0;
+    double dt = t - (double)t0;
+    return (1. - ds) * (1. - dt) * get_pixel(tx, level, w, h, s0, t0) +
+           (1. - ds) * dt * get_pixel(tx, level, w, h, s0, sat_inc(t0)) +
+           ds * (1. - dt) * get_pixel(tx, level, w, h, sat_inc(s0), t0) +
+           ds * dt * get_pixel(tx, level, w, h, sat_inc(s0), sat_inc(t0));
+}
+__device__ D3 sample_mipmap(const Texture& tx, double u, double v, double dudx, double dvdx, double dudy,
+                            double dvdy) {  // mipmap.rs:117-141
+    uint32_t n_levels = tx.n_levels;
+    double width = fmax(fmax(fabs(dudx), fabs(dvdx)), fmax(fabs(dudy), fabs(dvdy)));
+    double level = (double)n_levels - 1. + log2(fmax(width, 1e-8));
+    if (level < 0.) {
+        return tex_triangle(tx, 0, u, v);
+    } else if (level >= (double)n_levels - 1.) {
+        const double* p = tx.texels + (size_t)tx.offset[n_levels - 1] * 3;
+        return mk(p[0], p[1], p[2]);
+    } else {
+        uint32_t ilevel = f64_as_usize_sat(floor(level));
+        double delta = level - (double)ilevel;
+        D3 a = tex_triangle(tx, ilevel, u, v), b = tex_triangle(tx, ilevel + 1, u, v);
+        return (1. - delta) * a + delta * b;
+    }
+}
+
+// surface.rs:112-123
+__device__ __forceinline__ void solve2x2(double a00, double a01, double a10, double a11, double b0, double b1,
+                                         double& x0, double& x1) {
+    double det = a00 * a11 - a01 * a10;
+    if (fabs(det) < 1e-10) { x0 = 0.; x1 = 0.; return; }
+    double r0 = (a11 * b0 - a01 * b1) / det;
+    double r1 = (a00 * b1 - a10 * b0) / det;
+    if (r0 != r0 || r1 != r1) { x0 = 0.; x1 = 0.; return; }
+    x0 = r0; x1 = r1;
+}
+
+// Diffuse colour of a textured Lambertian at a hit: uv interpolation + dpdu/dpdv
+// (triangle_mesh.rs:128-138), ray differentials (surface.rs:59-109), material.rs:100-111.
+// `has_diffs`: the ray carries differentials (primary ray with CONFIG.use_diffs); secondary rays
+// have all-zero differential rays (main.rs:314 Ray::new), which surface.rs:72-80 turns into zeros.
+__device__ D3 textured_color(const Scene& sc, const Material& m, const TriV& tr, uint32_t leaf, D3 o, D3 d,
+                             D3 position, D3 normal, bool has_diffs, D3 rx_dir, D3 ry_dir) {
+    double uv[6];
+    if (sc.uvs) {
+        const float2* up = sc.uvs + (size_t)leaf * 3;
+        float2 a = up[0], b = up[1], c = up[2];
+        uv[0] = (double)a.x; uv[1] = (double)a.y; uv[2] = (double)b.x; uv[3] = (double)b.y; uv[4] = (double)c.x; uv[5] = (double)c.y;
+    } else {
+        uv[0] = 0.; uv[1] = 0.; uv[2] = 1.0; uv[3] = 0.; uv[4] = 1.; uv[5] = 1.;
+    }
+    // barycentrics, triangle_mesh.rs:118-122
+    D3 e0 = tr.v1 - tr.v0;
+    D3 e1 = tr.v0 - tr.v2;
+    D3 gn = cross(e0, e1);
+    D3 tmp = cross(tr.v0 - o, d);
+    double denom = 1. / dot(d, gn);
+    double v = dot(tmp, e1) * denom;
+    double w = dot(tmp, e0) * denom;
+    double u = 1. - v - w;
+    double tu = uv[0] * u + uv[2] * v + uv[4] * w;
+    double tv = uv[1] * u + uv[3] * v + uv[5] * w;
+    double dudx = 0., dvdx = 0., dudy = 0., dvdy = 0.;
+    if (has_diffs) {
+        D3 dp02 = tr.v0 - tr.v2, dp12 = tr.v1 - tr.v2;
+        double duv02x = uv[0] - uv[4], duv02y = uv[1] - uv[5], duv12x = uv[2] - uv[4], duv12y = uv[3] - uv[5];
+        double determinant = duv02x * duv12y - duv02y * duv12x;
+        double inverse_det = 1. / determinant;
+        D3 dpdu = (duv12y * dp02 - duv02y * dp12) * inverse_det;
+        D3 dpdv = (-duv12x * dp02 + duv02x * dp12) * inverse_det;
+        // surface.rs:65-84 (rx_origin = ry_origin = eye = o for a primary ray)
+        double dd = dot(normal, position);
+        double tx = -(dot(normal, o) - dd) / dot(normal, rx_dir);
+        double ty = -(dot(normal, o) - dd) / dot(normal, ry_dir);
+        bool bad = isinf(tx) || tx != tx || isinf(ty) || ty != ty;
+        if (!bad) {
+            D3 px = o + tx * rx_dir;
+            D3 py = o + ty * ry_dir;
+            D3 dpdx = px - position;
+            D3 dpdy = py - position;
+            int d0, d1;
+            if (fabs(normal.x) > fabs(normal.y) && fabs(normal.x) > fabs(normal.z)) { d0 = 1; d1 = 2; }
+            else if (fabs(normal.y) > fabs(normal.z)) { d0 = 0; d1 = 2; }
+            else { d0 = 0; d1 = 1; }
+            double a00 = comp(dpdu, d0), a01 = comp(dpdv, d0), a10 = comp(dpdu, d1), a11 = comp(dpdv, d1);
+            solve2x2(a00, a01, a10, a11, comp(dpdx, d0), comp(dpdx, d1), dudx, dvdx);
+            solve2x2(a00, a01, a10, a11, comp(dpdy, d0), comp(dpdy, d1), dudy, dvdy);
+        }
+    }
+    return sample_mipmap(sc.texs[m.tex], tu, tv, dudx, dvdx, dudy, dvdy);
+}
+
+// ------------------------------------------------------------------------------------------------
+// microfacet.rs — Beckmann + conductor Fresnel.  The Fresnel terms are fixed by microfacet.rs:45
+// (ior 32, absorption 0.1, ior_t 1) and identical in the three channels, so one channel is computed.
+__device__ __forceinline__ double conductor32(double cos_theta_i) {  // microfacet.rs:264-285
+    const double eta = 1. / 32.;
+    const double etak = 0.1 / 32.;
+    double cosThetaI2 = cos_theta_i * cos_theta_i;
+    double sinThetaI2 = 1. * (1. - cosThetaI2);
+    double eta2 = eta * eta;
+    double etak2 = etak * etak;
+    double t0 = eta2 - etak2 - sinThetaI2;
+    double a2plusb2 = sqrt(t0 * t0 + 4. * eta2 * etak2);
+    double t1 = a2plusb2 + 1. * cosThetaI2;
+    double a = sqrt(0.5 * (a2plusb2 + t0));
+    double t2 = 2. * cos_theta_i * a;
+    double Rs = (t1 - t2) / (t1 + t2);
+    double t3 = cosThetaI2 * a2plusb2 + sinThetaI2 * sinThetaI2;
+    double t4 = t2 * sinThetaI2;
+    double Rp = Rs * (t3 - t4) / (t3 + t4);
+    return 0.5 * (Rp + Rs);
+}
+__device__ __forceinline__ double beckmann_D(double width, D3 m, D3 n) {  // microfacet.rs:161-173
+    double cos_theta_m = dot(m, n);
+    if (cos_theta_m <= 0.) return 0.;
+    double c2 = cos_theta_m * cos_theta_m;
+    double cos4theta_m = c2 * c2;
+    double theta_m = acos(cos_theta_m);
+    double tan_m = tan(theta_m);
+    double tan2theta_m = tan_m * tan_m;
+    double alpha2 = width * width;
+    return exp(-tan2theta_m / alpha2) / (PT_PI * alpha2 * cos4theta_m);
+}
+__device__ __forceinline__ double beckmann_G1(double width, D3 w, D3 m, D3 n) {  // microfacet.rs:175-189
+    double cos_theta_v = dot(w, n);
+    if (dot(w, m) / cos_theta_v <= 0.0) return 0.;
+    double theta_v = acos(cos_theta_v);
+    double a = 1. / (width * tan(theta_v));
+    if (a >= 1.6) return 1.;
+    return (3.535 * a + 2.181 * a * a) / (1. + 2.276 * a + 2.577 * a * a);
+}
+__device__ D3 glossy_f(double width, D3 reflectance, D3 wo, D3 wi, D3 n) {  // microfacet.rs:64-93
+    D3 wh = normalize(wo + wi);
+    double cos_theta_o = fabs(dot(wo, n));
+    double cos_theta_i = fabs(dot(wi, n));
+    if (cos_theta_i == 0. || cos_theta_o == 0.) return mk(0., 0., 0.);
+    if (wh.x == 0. && wh.y == 0. && wh.z == 0.) return mk(0., 0., 0.);
+    double fresnel = conductor32(dot(wo, wh));
+    double dd = beckmann_D(width, wh, n);
+    D3 hv = normalize(wi + wo);  // microfacet.rs:105
+    double t = beckmann_G1(width, wo, hv, n) * beckmann_G1(width, wi, hv, n);
+    double g = t < 0. ? 0. : (t > 1. ? 1. : t);
+    return reflectance * dd * g * mk(fresnel, fresnel, fresnel) / (4. * cos_theta_i * cos_theta_o);
+}
+__device__ __forceinline__ double glossy_pdf_dir(double width, D3 wo, D3 wi, D3 n) {
+    D3 h = normalize(wo + wi);
+    return beckmann_D(width, h, n) * fabs(dot(h, n)) / (4. * dot(wo, h));
+}
+
+struct Brdf {
+    D3 f, wi;
+    double pdf;
+};
+// material.rs:9-23 + 37-58
+__device__ __forceinline__ Brdf lambertian_sample(D3 color, D3 n, double xi1, double xi2) {
+    double cos_theta = sqrt(xi1);
+    double sin_theta = sqrt(1.0 - xi1);
+    double phi = 2.0 * PT_PI * xi2;
+    double sp, cp;
+    sincos(phi, &sp, &cp);
+    D3 wi = rotate_to(mk(sin_theta * cp, sin_theta * sp, cos_theta), n);
+    return {color * PT_FRAC_1_PI, wi, dot(n, wi) * PT_FRAC_1_PI};
+}
+// microfacet.rs:52-62 + 147-159
+__device__ Brdf glossy_sample(double width, D3 reflectance, D3 ray_dir, D3 n, double xi1, double xi2) {
+    D3 wo = -ray_dir;
+    double tan_theta_sqr = -width * width * log(1. - xi1);
+    double phi = 2.0 * PT_PI * xi2;
+    double cos_theta = 1. / sqrt(1. + tan_theta_sqr);
+    double sin_theta = sqrt(fmax(0., 1. - cos_theta * cos_theta));
+    double sp, cp;
+    sincos(phi, &sp, &cp);
+    D3 h = normalize(rotate_to(mk(sin_theta * cp, sin_theta * sp, cos_theta), n));
+    D3 wi = reflect(-wo, h);
+    double pdf = beckmann_D(width, h, n) * fabs(dot(h, n)) / (4. * dot(wo, h));
+    D3 f = glossy_f(width, reflectance, wo, wi, n);
+    return {f, wi, pdf};
+}
+
+// Everything main.rs:303-311 needs at a hit.
+struct ShadePoint {
+    D3 position, normal, emission;
+    Brdf bs;
+    D3 diffuse;  // Lambertian colour after the texture lookup (NEE evaluates the BRDF with it)
+};
+__device__ __forceinline__ void hit_geometry(const Scene& sc, uint32_t leaf, D3 o, D3 d, double t, TriV& tr,
+                                             uint32_t& mat, D3& position, D3& normal) {
+    const float4* tp = sc.tris + (size_t)leaf * 3;
+    float4 a = tp[0], b = tp[1], c = tp[2];
+    tr = widen(a, b, c);
+    mat = (uint32_t)__float_as_int(b.w);
+    D3 gn = cross(tr.v1 - tr.v0, tr.v0 - tr.v2);
+    position = o + d * t;         // triangle_mesh.rs:140
+    normal = -normalize(gn);      // triangle_mesh.rs:141
+}
+__device__ __forceinline__ D3 diffuse_of(const Scene& sc, const Material& m, const TriV& tr, uint32_t leaf, D3 o,
+                                         D3 d, D3 position, D3 normal, const Frame& fr, bool primary,
+                                         uint32_t pixel, uint32_t s) {
+    if (m.tex < 0) return ld3(m.color);
+    bool has_diffs = primary && (fr.flags & PT_FLAG_USE_DIFFS);
+    D3 rx = mk(0., 0., 0.), ry = rx;
+    if (has_diffs) {  // scene.rs:47-54
+        PixelArgs a = pixel_args(pixel % fr.width, pixel / fr.width, fr.width, fr.height, fr.jitter[2 * s],
+                                 fr.jitter[2 * s + 1]);
+        rx = camera_dir(sc.cam, a.x + a.ddx, a.y);
+        ry = camera_dir(sc.cam, a.x, a.y + a.ddy);
+    }
+    return textured_color(sc, m, tr, leaf, o, d, position, normal, has_diffs, rx, ry);
+}
+
+// ------------------------------------------------------------------------------------------------
+// block-wide compaction: wave64 ballot + mbcnt prefix, one atomic per block
+__device__ __forceinline__ uint32_t compact_slot(bool alive, uint32_t* counter, uint32_t* lds /* kBlock/64 + 1 */) {
+    unsigned long long m = __ballot(alive);
+    uint32_t lane_prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) lds[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) {
+            uint32_t c = lds[w];
+            lds[w] = total;
+            total += c;
+        }
+        lds[kBlock / 64] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t pos = lds[kBlock / 64] + lds[wave] + lane_prefix;
+    __syncthreads();
+    return pos;
+}
+
+// shade: one lane per live path.  FIRST = bounce 0 (queue index == slot, throughput == 1).
+template <bool FIRST, bool NEE>
+__global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t bounce, Queue in, Hits hits,
+                                                  const uint32_t* __restrict__ count, uint32_t n_max, Queue out,
+                                                  uint32_t* out_count, ShadowQueue sq, uint32_t* sq_count,
+                                                  Sample3 ls) {
+    __shared__ uint32_t lds_a[kBlock / 64 + 1];
+    __shared__ uint32_t lds_b[kBlock / 64 + 1];
+    uint32_t n = count ? min(*count, n_max) : n_max;
+    if (blockIdx.x * kBlock >= n) return;  // whole block idle
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    bool active = i < n;
+    bool alive = false, shadow = false;
+    uint32_t slot = 0;
+    D3 n_o = mk(0, 0, 0), n_d = n_o, n_T = n_o;
+    double n_pdf = 0.;
+    D3 s_d = n_o, s_c = n_o;
+    double s_tmax = 0.;
+    if (active) {
+        slot = FIRST ? i : in.slot[i];
+        D3 o = mk(in.o[0][i], in.o[1][i], in.o[2][i]);
+        D3 d = mk(in.d[0][i], in.d[1][i], in.d[2][i]);
+        D3 T = FIRST ? mk(1., 1., 1.) : mk(in.T[0][i], in.T[1][i], in.T[2][i]);
+        uint32_t leaf = hits.tri[i];
+        D3 add;  // what main.rs:299 / :307 adds to color_result
+        if (leaf == PT_MISS) {
+            add = T * ld3(sc.background);  // main.rs:299
+        } else {
+            double t = hits.t[i];
+            TriV tr;
+            uint32_t mat;
+            D3 position, normal;
+            hit_geometry(sc, leaf, o, d, t, tr, mat, position, normal);
+            const Material& m = sc.mats[mat];
+            D3 le = m.kind == PT_MAT_GLOSSY ? mk(0., 0., 0.) : ld3(m.emission);  // microfacet.rs:33-35
+            add = T * le;  // main.rs:307
+            uint32_t s = slot / fr.n_tile_pixels, p = slot - s * fr.n_tile_pixels;
+            uint32_t ty = p / fr.tile_w, tx = p - ty * fr.tile_w;
+            uint32_t pixel = (fr.y0 + ty) * fr.width + fr.x0 + tx;
+            uint64_t sample = fr.sample_base + s;
+            if (NEE && !FIRST && (le.x != 0. || le.y != 0. || le.z != 0.)) {
+                // MIS weight of a BRDF-sampled hit on a light (balance heuristic)
+                D3 ln = normalize(cross(tr.v1 - tr.v0, tr.v2 - tr.v0));
+                double cos_l = fabs(dot(ln, d));
+                double p_l = cos_l <= 0. ? 0. : t * t / (sc.light_area * cos_l);
+                double pp = in.prev_pdf[i];
+                double wgt = pp > 0. ? pp / (pp + p_l) : 0.;
+                add = T * le * wgt;
+            }
+            if (bounce < fr.max_bounces) {  // the reference also samples at the last hit; the result is unused
+                D3 diffuse = mk(0., 0., 0.);
+                if (m.kind != PT_MAT_GLOSSY) diffuse = diffuse_of(sc, m, tr, leaf, o, d, position, normal, fr, FIRST, pixel, s);
+                if (NEE && sc.n_lights) {
+                    double r0, r1;
+                    uniform2(fr.seed, pixel, sample, bounce, STREAM_LIGHT, r0, r1);
+                    double target = r0 * sc.light_area;
+                    uint32_t lo_i = 0, hi_i = sc.n_lights - 1;  // first light with cdf > target, else last
+                    while (lo_i < hi_i) {
+                        uint32_t mid = (lo_i + hi_i) >> 1;
+                        if (sc.lights[mid].cdf <= target) lo_i = mid + 1; else hi_i = mid;
+                    }
+                    const Light& L = sc.lights[lo_i];
+                    double cdf_lo = lo_i ? sc.lights[lo_i - 1].cdf : 0.;
+                    double u1 = (target - cdf_lo) / (L.cdf - cdf_lo);
+                    if (!(u1 >= 0.)) u1 = 0.;
+                    if (u1 > 1.) u1 = 1.;
+                    double su = sqrt(u1);
+                    double b0 = 1. - su, b1 = r1 * su;
+                    D3 lp = ld3(L.v0) * b0 + ld3(L.v1) * b1 + ld3(L.v2) * (1. - b0 - b1);
+                    D3 diff = lp - position;
+                    double dist = length(diff);
+                    D3 wl = diff / dist;
+                    D3 wo = -d;
+                    double p_b;
+                    if (m.kind == PT_MAT_GLOSSY) {
+                        double pg = glossy_pdf_dir(m.width, wo, wl, normal);
+                        p_b = pg > 0. ? pg : 0.;
+                    } else {
+                        double c = dot(normal, wl);
+                        p_b = c > 0. ? c * PT_FRAC_1_PI : 0.;
+                    }
+                    double cos_l = fabs(dot(ld3(L.normal), wl));
+                    double p_l = cos_l <= 0. ? 0. : dist * dist / (sc.light_area * cos_l);
+                    if (p_l > 0. && p_b > 0. && dist > 0.) {
+                        D3 f = m.kind == PT_MAT_GLOSSY ? glossy_f(m.width, ld3(m.color), wo, wl, normal)
+                                                       : diffuse * PT_FRAC_1_PI;
+                        double cosn = fabs(dot(wl, normal));
+                        double wgt = p_l / (p_l + p_b);
+                        s_c = T * f * ld3(L.emission) * (cosn * wgt / p_l);
+                        s_d = wl;
+                        s_tmax = dist * (1. - 1e-9);
+                        shadow = true;
+                    }
+                }
+                double xi1, xi2;
+                uniform2(fr.seed, pixel, sample, bounce, STREAM_BRDF, xi1, xi2);
+                Brdf bs = m.kind == PT_MAT_GLOSSY ? glossy_sample(m.width, ld3(m.color), d, normal, xi1, xi2)
+                                                  : lambertian_sample(diffuse, normal, xi1, xi2);
+                n_T = T * (bs.f * fabs(dot(bs.wi, normal)) / bs.pdf);  // main.rs:311
+                n_o = position;                                        // main.rs:314
+                n_d = bs.wi;
+                n_pdf = bs.pdf > 0. ? bs.pdf : 0.;
+                alive = true;
+            }
+        }
+        // color_result += add.  Adding +-0 never changes the sum (it starts at +0), NaN != 0 is true.
+        if (FIRST) {
+            ls.c[0][slot] = 0. + add.x; ls.c[1][slot] = 0. + add.y; ls.c[2][slot] = 0. + add.z;
+        } else if (add.x != 0. || add.y != 0. || add.z != 0.) {
+            ls.c[0][slot] += add.x; ls.c[1][slot] += add.y; ls.c[2][slot] += add.z;
+        }
+    }
+    if (bounce >= fr.max_bounces) return;  // uniform: nothing continues
+    uint32_t pos = compact_slot(alive, out_count, lds_a);
+    if (alive) {
+        out.o[0][pos] = n_o.x; out.o[1][pos] = n_o.y; out.o[2][pos] = n_o.z;
+        out.d[0][pos] = n_d.x; out.d[1][pos] = n_d.y; out.d[2][pos] = n_d.z;
+        out.T[0][pos] = n_T.x; out.T[1][pos] = n_T.y; out.T[2][pos] = n_T.z;
+        out.slot[pos] = slot;
+        if (NEE) out.prev_pdf[pos] = n_pdf;
+    }
+    if (NEE) {
+        uint32_t spos = compact_slot(shadow, sq_count, lds_b);
+        if (shadow) {
+            sq.o[0][spos] = n_o.x; sq.o[1][spos] = n_o.y; sq.o[2][spos] = n_o.z;
+            sq.d[0][spos] = s_d.x; sq.d[1][spos] = s_d.y; sq.d[2][spos] = s_d.z;
+            sq.tmax[spos] = s_tmax;
+            sq.c[0][spos] = s_c.x; sq.c[1][spos] = s_c.y; sq.c[2][spos] = s_c.z;
+            sq.slot[spos] = slot;
+        }
+    }
+}
+
+// accumulate: main.rs:434-436, frames of the batch added in index order (deterministic f64 sum)
+__global__ __launch_bounds__(kBlock) void k_accumulate(Frame fr, Sample3 ls, double* __restrict__ accum) {
+    uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= fr.n_tile_pixels) return;
+    uint32_t ty = p / fr.tile_w, tx = p - ty * fr.tile_w;
+    size_t pix = (size_t)(fr.y0 + ty) * fr.width + fr.x0 + tx;
+    double r = accum[pix * 3], g = accum[pix * 3 + 1], b = accum[pix * 3 + 2];
+    bool drop = (fr.flags & PT_FLAG_DROP_NONFINITE) != 0;
+    for (uint32_t s = 0; s < fr.n_samples; ++s) {
+        size_t k = (size_t)s * fr.n_tile_pixels + p;
+        double cr = ls.c[0][k], cg = ls.c[1][k], cb = ls.c[2][k];
+        if (drop && !(isfinite(cr) && isfinite(cg) && isfinite(cb))) continue;
+        r += cr; g += cg; b += cb;
+    }
+    accum[pix * 3] = r; accum[pix * 3 + 1] = g; accum[pix * 3 + 2] = b;
+}
+
+// main.rs:402-405 + 469-481 with samples_per_pixel = 1 (main.rs:386): one jitter pair per frame,
+// shared by all pixels; step = 1, x drawn before y, scaled by the pixel size (not twice it).
+__global__ void k_jitter(uint64_t seed, uint64_t sample_begin, uint32_t n, double psx, double psy, double* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double r0, r1;
+    uniform2(seed, 0u, sample_begin + i, 0u, STREAM_JITTER, r0, r1);
+    double step = 1. / 1.;
+    double jx = step * (r0 + 0.) - 1. / 2.;
+    double jy = step * (r1 + 0.) - 1. / 2.;
+    out[2 * i] = jx * psx;
+    out[2 * i + 1] = jy * psy;
+}
+
+// ------------------------------------------------------------------------------------------------
+// parity-only kernels
+__global__ void k_leaf_to_global(Scene sc, uint32_t* tri, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t leaf = tri[i];
+    if (leaf != PT_MISS) tri[i] = (uint32_t)__float_as_int(sc.tris[(size_t)leaf * 3].w);
+}
+
+__global__ void k_sample_brdf(Scene sc, Frame fr, uint32_t bounce, const double* __restrict__ rays,
+                              const uint32_t* __restrict__ tri_global, const double* __restrict__ tt,
+                              const uint32_t* __restrict__ pixel_in, uint32_t n, double* f, double* wi, double* pdf,
+                              double* emission, double* position_out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* r = rays + (size_t)i * 8;
+    D3 o = mk(r[0], r[1], r[2]), d = mk(r[3], r[4], r[5]);
+    uint32_t leaf = sc.leaf_of[tri_global[i]];
+    TriV tr;
+    uint32_t mat;
+    D3 position, normal;
+    hit_geometry(sc, leaf, o, d, tt[i], tr, mat, position, normal);
+    const Material& m = sc.mats[mat];
+    uint32_t pixel = pixel_in[i];
+    D3 diffuse = mk(0., 0., 0.);
+    if (m.kind != PT_MAT_GLOSSY) diffuse = diffuse_of(sc, m, tr, leaf, o, d, position, normal, fr, bounce == 0, pixel, 0);
+    double xi1, xi2;
+    uniform2(fr.seed, pixel, fr.sample_base, bounce, STREAM_BRDF, xi1, xi2);
+    Brdf bs = m.kind == PT_MAT_GLOSSY ? glossy_sample(m.width, ld3(m.color), d, normal, xi1, xi2)
+                                      : lambertian_sample(diffuse, normal, xi1, xi2);
+    D3 le = m.kind == PT_MAT_GLOSSY ? mk(0., 0., 0.) : ld3(m.emission);
+    f[3 * i] = bs.f.x; f[3 * i + 1] = bs.f.y; f[3 * i + 2] = bs.f.z;
+    wi[3 * i] = bs.wi.x; wi[3 * i + 1] = bs.wi.y; wi[3 * i + 2] = bs.wi.z;
+    pdf[i] = bs.pdf;
+    emission[3 * i] = le.x; emission[3 * i + 1] = le.y; emission[3 * i + 2] = le.z;
+    position_out[3 * i] = position.x; position_out[3 * i + 1] = position.y; position_out[3 * i + 2] = position.z;
+}
+
+__global__ void k_texture_lookup(Scene sc, uint32_t tex, const double* __restrict__ uv,
+                                 const double* __restrict__ duvdx, const double* __restrict__ duvdy, uint32_t n,
+                                 double* rgb) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    D3 c = sample_mipmap(sc.texs[tex], uv[2 * i], uv[2 * i + 1], duvdx[2 * i], duvdx[2 * i + 1], duvdy[2 * i],
+                         duvdy[2 * i + 1]);
+    rgb[3 * i] = c.x; rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+static inline uint32_t blocks_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
+
+void launch_jitter(uint64_t seed, uint64_t sample_begin, uint32_t n, double psx, double psy, double* out,
+                   hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_jitter, dim3(blocks_for(n)), dim3(kBlock), 0, st, seed, sample_begin, n, psx, psy, out);
+}
+void launch_generate(const Scene& sc, const Frame& fr, Queue q, hipStream_t st) {
+    uint32_t n = fr.n_tile_pixels * fr.n_samples;
+    if (!n) return;
+    hipLaunchKernelGGL(k_generate, dim3(blocks_for(n)), dim3(kBlock), 0, st, sc, fr, q);
+}
+void launch_generate_rays(const Scene& sc, const Frame& fr, double* rays_out, hipStream_t st) {
+    if (!fr.n_tile_pixels) return;
+    hipLaunchKernelGGL(k_generate_rays, dim3(blocks_for(fr.n_tile_pixels)), dim3(kBlock), 0, st, sc, fr, rays_out);
+}
+void launch_extend(const Scene& sc, Queue q, const double* tmin, const double* tmax, const uint32_t* count,
+                   uint32_t n_max, Hits hits, Counters* ctr, bool stats, hipStream_t st) {
+    if (!n_max) return;
+    if (stats)
+        hipLaunchKernelGGL(k_extend<true>, dim3(blocks_for(n_max)), dim3(kBlock), 0, st, sc, q, tmin, tmax, count, n_max, hits, ctr);
+    else
+        hipLaunchKernelGGL(k_extend<false>, dim3(blocks_for(n_max)), dim3(kBlock), 0, st, sc, q, tmin, tmax, count, n_max, hits, ctr);
+}
+void launch_shade(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, Hits hits, const uint32_t* count,
+                  uint32_t n_max, Queue out, uint32_t* out_count, ShadowQueue sq, uint32_t* sq_count, Sample3 ls,
+                  hipStream_t st) {
+    if (!n_max) return;
+    bool nee = (fr.flags & PT_FLAG_NEE) != 0 && sc.n_lights > 0;
+    dim3 g(blocks_for(n_max)), b(kBlock);
+    if (bounce == 0) {
+        if (nee) hipLaunchKernelGGL((k_shade<true, true>), g, b, 0, st, sc, fr, bounce, in, hits, count, n_max, out, out_count, sq, sq_count, ls);
+        else hipLaunchKernelGGL((k_shade<true, false>), g, b, 0, st, sc, fr, bounce, in, hits, count, n_max, out, out_count, sq, sq_count, ls);
+    } else {
+        if (nee) hipLaunchKernelGGL((k_shade<false, true>), g, b, 0, st, sc, fr, bounce, in, hits, count, n_max, out, out_count, sq, sq_count, ls);
+        else hipLaunchKernelGGL((k_shade<false, false>), g, b, 0, st, sc, fr, bounce, in, hits, count, n_max, out, out_count, sq, sq_count, ls);
+    }
+}
+void launch_shadow(const Scene& sc, ShadowQueue sq, const uint32_t* count, uint32_t n_max, Sample3 ls, Counters* ctr,
+                   hipStream_t st) {
+    if (!n_max) return;
+    hipLaunchKernelGGL(k_shadow, dim3(blocks_for(n_max)), dim3(kBlock), 0, st, sc, sq, count, n_max, ls, ctr);
+}
+void launch_accumulate(const Frame& fr, Sample3 ls, double* accum, hipStream_t st) {
+    if (!fr.n_tile_pixels) return;
+    hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(fr.n_tile_pixels)), dim3(kBlock), 0, st, fr, ls, accum);
+}
+void launch_leaf_to_global(const Scene& sc, uint32_t* tri, uint32_t n, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_leaf_to_global, dim3(blocks_for(n)), dim3(kBlock), 0, st, sc, tri, n);
+}
+void launch_sample_brdf(const Scene& sc, const Frame& fr, uint32_t bounce, const double* rays, const uint32_t* tri,
+                        const double* t, const uint32_t* pixel, uint32_t n, double* f, double* wi, double* pdf,
+                        double* emission, double* position, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_sample_brdf, dim3(blocks_for(n)), dim3(kBlock), 0, st, sc, fr, bounce, rays, tri, t, pixel, n, f, wi, pdf, emission, position);
+}
+void launch_texture_lookup(const Scene& sc, uint32_t tex, const double* uv, const double* duvdx, const double* duvdy,
+                           uint32_t n, double* rgb, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_texture_lookup, dim3(blocks_for(n)), dim3(kBlock), 0, st, sc, tex, uv, duvdx, duvdy, n, rgb);
+}
+
+}  // namespace ptd
+
+extern "C" void pt_rng_uniform2(uint64_t seed, uint32_t pixel, uint64_t sample, uint32_t bounce, uint32_t stream,
+                                double out[2]) {
+    ptd::uniform2(seed, pixel, sample, bounce, stream, out[0], out[1]);
+}
