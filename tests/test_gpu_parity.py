@@ -1,0 +1,184 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle.
+
+Bar (prompt §3 / BASELINE.json north_star): primary-ray generation, hit triangle ids and hit
+distances are bit-exact; images agree within a stated tolerance because sin/cos come from
+different math libraries on the two sides (glibc vs ROCm ocml).
+"""
+import numpy as np
+import pytest
+
+import pathtracer_amd as pt
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+SCENES = ["CornellBox", "Test", "glossy_planes", "cornell_box"]
+
+
+@pytest.fixture(scope="module")
+def scenes(gpu):
+    out = {}
+    for name in SCENES:
+        data = pt.scene_data(name)
+        out[name] = (data, pt.Scene(data, device=gpu), O.OracleScene(data))
+    return out
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint64)
+
+
+@pytest.mark.parametrize("name", SCENES)
+@pytest.mark.parametrize("dims", [(128, 128), (192, 108)])
+def test_generate_rays_bit_exact(scenes, name, dims):
+    data, scene, oracle = scenes[name]
+    cfg = pt.Config(width=dims[0], height=dims[1], seed=3)
+    for sample in (0, 5):
+        got = scene.generate_rays(cfg, sample)
+        ref = oracle.generate_rays(cfg, sample)
+        assert got.tobytes() == ref.tobytes()
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_primary_hits_bit_exact(scenes, name):
+    data, scene, oracle = scenes[name]
+    cfg = pt.Config(dim=128, seed=11)
+    rays = oracle.generate_rays(cfg, 1)
+    tri, t = scene.trace_closest(rays)
+    rtri, rt = oracle.trace_closest(rays, use_bvh=False)
+    assert np.array_equal(tri, rtri)
+    assert np.array_equal(bits(t), bits(rt))
+    if name != "cornell_box":
+        assert (tri != pt.PT_MISS).mean() > 0.3
+
+
+def random_rays(data, n, seed):
+    rng = np.random.default_rng(seed)
+    lo, hi = data.verts.min(axis=0).astype(np.float64), data.verts.max(axis=0).astype(np.float64)
+    ext = np.maximum(hi - lo, 1e-3)
+    o = lo - 0.25 * ext + rng.random((n, 3)) * 1.5 * ext
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    # a share of axis-aligned and zero-component directions (slab test edge cases)
+    k = n // 8
+    d[:k] = 0.0
+    d[np.arange(k), rng.integers(0, 3, k)] = rng.choice([-1.0, 1.0], k)
+    d[k:2 * k, rng.integers(0, 3)] = 0.0
+    d[k:2 * k] /= np.maximum(np.linalg.norm(d[k:2 * k], axis=1, keepdims=True), 1e-30)
+    # a share of rays starting exactly on vertices / triangle centroids (secondary-ray-like origins)
+    tris = data.verts[data.tris].astype(np.float64)
+    pick = rng.integers(0, tris.shape[0], k)
+    o[2 * k:3 * k] = tris[pick].mean(axis=1)
+    o[3 * k:4 * k] = tris[pick, 0]
+    return pt.make_rays(o, d)
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_random_rays_bit_exact(scenes, name):
+    data, scene, oracle = scenes[name]
+    rays = random_rays(data, 20000, seed=5)
+    tri, t = scene.trace_closest(rays)
+    rtri, rt = oracle.trace_closest(rays, use_bvh=False)
+    assert np.array_equal(tri, rtri)
+    assert np.array_equal(bits(t), bits(rt))
+
+
+def test_tmin_tmax_respected(scenes):
+    data, scene, oracle = scenes["CornellBox"]
+    rays = random_rays(data, 4000, seed=9)
+    rays["t_min"] = 0.3
+    rays["t_max"] = 0.9
+    tri, t = scene.trace_closest(rays)
+    rtri, rt = oracle.trace_closest(rays)
+    assert np.array_equal(tri, rtri) and np.array_equal(bits(t), bits(rt))
+    hit = tri != pt.PT_MISS
+    assert hit.any() and (~hit).any()
+    assert np.all(t[hit] >= 0.3) and np.all(t[hit] <= 0.9)
+    assert np.all(t[~hit] == 0.9)  # a miss leaves t_max untouched (scene.rs:61 &mut Ray)
+
+
+def test_exact_ties_lowest_id_wins(gpu):
+    # two coincident triangles with different ids and one shared-edge pair: bit-identical t
+    verts = np.array([[0, 0, 1], [1, 0, 1], [0, 1, 1], [1, 1, 1]], np.float32)
+    tris = np.array([[0, 1, 2], [0, 1, 2], [1, 3, 2], [0, 1, 2]], np.uint32)
+    mats = np.zeros(1, pt.MATERIAL_DTYPE)
+    mats["tex"] = -1
+    data = pt.SceneData(verts, tris, np.zeros(4, np.uint32), mats)
+    scene, oracle = pt.Scene(data, gpu), O.OracleScene(data)
+    o = np.array([[0.2, 0.2, 0.0], [0.5, 0.5, 0.0], [0.9, 0.9, 0.0]])
+    d = np.array([[0, 0, 1.0]] * 3)
+    rays = pt.make_rays(o, d)
+    tri, t = scene.trace_closest(rays)
+    rtri, rt = oracle.trace_closest(rays)
+    assert np.array_equal(tri, rtri) and np.array_equal(bits(t), bits(rt))
+    assert tri[0] == 0 and tri[2] == 2
+
+
+@pytest.mark.parametrize("name", ["CornellBox", "Test"])
+def test_render_matches_oracle(scenes, name):
+    data, scene, oracle = scenes[name]
+    cfg = pt.Config(dim=96, samples_pr_pixel=4, bounces=2, seed=2)
+    img = scene.render(cfg)
+    ref = oracle.render(cfg)
+    assert np.isfinite(img).all()
+    # tolerance: sin/cos differ by <= 1-2 ulp between ocml and glibc; a path whose hit flips
+    # across a triangle edge is rare.  Require 99.9 % of values within 1e-9 relative and a
+    # near-identical mean.
+    bad = np.abs(img - ref) > 1e-9 * np.maximum(1.0, np.abs(ref))
+    assert bad.mean() < 1e-3
+    assert abs(img.mean() - ref.mean()) <= 1e-6 * max(1.0, ref.mean())
+    assert ref.mean() > 0.01
+
+
+def test_render_batching_and_tiles_are_bitwise_invariant(scenes):
+    data, scene, _ = scenes["CornellBox"]
+    cfg = pt.Config(dim=64, samples_pr_pixel=6, seed=4)
+    whole = scene.render(cfg)
+    cfg_b = pt.Config(dim=64, samples_pr_pixel=6, seed=4, spp_per_batch=1)
+    one = scene.render(cfg_b)
+    assert whole.tobytes() == one.tobytes()
+    acc = np.zeros_like(whole)
+    for tile in [(0, 0, 40, 64), (40, 0, 64, 30), (40, 30, 64, 64)]:
+        scene.render(cfg, acc, tile=tile)
+    assert acc.tobytes() == whole.tobytes()
+    # sample ranges: 0..3 then 3..6 accumulate to the same sums in the same order
+    acc2 = scene.render(cfg, None, sample_begin=0, sample_count=3)
+    scene.render(cfg, acc2, sample_begin=3, sample_count=3)
+    assert acc2.tobytes() == whole.tobytes()
+
+
+def test_k1_cornell_box_obj_is_black(scenes):
+    # K1: models/cornell_box.obj has no mtllib -> black non-emissive quad -> zeros
+    data, scene, oracle = scenes["cornell_box"]
+    cfg = pt.Config(dim=64, samples_pr_pixel=3)
+    img = scene.render(cfg)
+    assert not img.any()
+    assert not oracle.render(cfg).any()
+
+
+def furnace(rho, emission):
+    # closed box, every surface Lambertian rho with emission E, camera inside
+    v = np.array([[x, y, z] for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)], np.float32)
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    tris = np.array([[q[0], q[1], q[2]] for q in quads] + [[q[0], q[2], q[3]] for q in quads], np.uint32)
+    # the reference scatters about the unflipped CCW normal (triangle_mesh.rs:141): wind every
+    # triangle so that normal points into the box, else paths leave through the walls
+    p = v[tris].astype(np.float64)
+    ccw = np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0])
+    outward = np.einsum("ij,ij->i", ccw, p.mean(axis=1)) > 0
+    tris[outward] = tris[outward][:, [0, 2, 1]]
+    mats = np.zeros(1, pt.MATERIAL_DTYPE)
+    mats["color"], mats["emission"], mats["tex"] = rho, emission, -1
+    cam = pt.Camera((0.1, -0.2, 0.05), (0.3, 0.2, 1.0), (0, 1, 0), 1.0)
+    return pt.SceneData(v, tris, np.zeros(len(tris), np.uint32), mats, camera=cam)
+
+
+def test_k2_furnace(gpu):
+    # K2: every sample = E * sum_{k=0..B} rho^k (main.rs:292-315 with f*cos/pdf == rho)
+    rho, E, B = 0.5, 2.0, 3
+    data = furnace(rho, E)
+    scene = pt.Scene(data, gpu)
+    cfg = pt.Config(dim=48, samples_pr_pixel=2, bounces=B)
+    img = scene.render(cfg) / 2
+    expect = E * sum(rho ** k for k in range(B + 1))
+    assert np.allclose(img, expect, rtol=1e-12, atol=0)
