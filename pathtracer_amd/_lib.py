@@ -117,7 +117,27 @@ class PtError(RuntimeError):
         self.code = code
 
 
+def _preload_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (same
+    SONAME as /opt/rocm's); if this library pulled in /opt/rocm's copy and torch later loaded its
+    own by path, two runtimes would fight over the GPU and the second to initialise sees no
+    device.  Loading torch's copy first (without importing torch) makes the dynamic loader reuse
+    it for libpt_hip.so and for a later ``import torch`` alike, so device pointers and streams can
+    be shared with torch tensors / torch.distributed."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def _load() -> C.CDLL:
+    _preload_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP library is the only implementation of pathtracer_amd "

@@ -283,8 +283,10 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
             if (d->tris[3 * i + k] >= d->n_verts) { set_error("triangle %u: vertex out of range", i); return PT_ERR_INVALID; }
     }
     int n_dev = 0;
-    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
-        set_error("no HIP device available (the HIP path is the only implementation)");
+    hipError_t dev_err = hipGetDeviceCount(&n_dev);
+    if (dev_err != hipSuccess || n_dev <= 0) {
+        set_error("no HIP device available: hipGetDeviceCount -> %s, %d devices (the HIP path is the only implementation)",
+                  hipGetErrorString(dev_err), n_dev);
         return PT_ERR_DEVICE;
     }
     if (device_id < 0 || device_id >= n_dev) { set_error("device %d out of range (%d devices)", device_id, n_dev); return PT_ERR_INVALID; }
