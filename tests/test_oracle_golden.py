@@ -1,0 +1,252 @@
+"""CPU tests of the oracle (oracle/pt_oracle.cpp) against
+  * the reference's own golden values (microfacet.rs:396-409, vec3.rs:408-424) — K9,
+  * the committed golden fixtures tests/golden/*.npz (independent numpy restatement) — K3,
+  * the known answers K1, K2, K4-K8 derived from the reference source,
+  * the published Philox4x32-10 known-answer vectors (Random123 kat_vectors).
+No GPU needed.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+import pathtracer_amd as pt
+import oracle_lib as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+# ---- K9: the reference's own unit tests ---------------------------------------------------------
+def test_reference_fresnel_golden():
+    # microfacet.rs:396-409: FresnelDielectric::new(1.5).dielectric(0.7071067811865476) ~ 0.0502399 (1e-4)
+    r = O.lib.orc_fresnel_dielectric(1.5, 0.7071067811865476)
+    assert abs(r - 0.0502399) < 0.0001
+
+
+def test_reference_refract_golden():
+    # vec3.rs:408-424
+    n = (0.0, 1.0, 0.0)
+    v = O.normalize((-1.0, -1.0, 0.0))
+    new_dir = O.refract(v, n, 1.0 / 1.5)
+    cos_t = float(np.dot(new_dir, n))
+    exp_t = -math.cos(0.4908825788)
+    assert cos_t - exp_t < 0.0001          # the reference's one-sided check
+    assert abs(cos_t - exp_t) < 1e-6       # and the two-sided one it meant
+
+
+# ---- RNG ----------------------------------------------------------------------------------------
+def test_philox_known_answers():
+    assert O.philox((0, 0), (0, 0, 0, 0)) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert O.philox((0xffffffff, 0xffffffff), (0xffffffff,) * 4) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert O.philox((0xa4093822, 0x299f31d0), (0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344)) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_uniform_is_53_bit_half_open():
+    for args in [(1, 0, 0, 0, 0), (7, 123, 2**40 + 5, 2, 1), (2**63 + 9, 2**32 - 1, 3, 60, 2)]:
+        u = O.rng_uniform2(*args)
+        for x in u:
+            assert 0.0 <= x < 1.0 and (x * 2**53) == int(x * 2**53)
+    a = [O.rng_uniform2(1, p, 0, 0, 0)[0] for p in range(4000)]
+    assert abs(np.mean(a) - 0.5) < 0.02
+
+
+# ---- K3: golden primary hits ---------------------------------------------------------------------
+@pytest.mark.parametrize("name,dim", [("CornellBox", 128), ("Test", 96), ("glossy_planes", 96)])
+def test_k3_primary_hits_match_golden(name, dim):
+    g = np.load(os.path.join(GOLDEN, f"primary_hits_{name}_{dim}.npz"))
+    data = pt.scene_data(name)
+    oracle = O.OracleScene(data)
+    rays = pt.make_rays(np.broadcast_to(np.array(data.camera.eye, np.float64), g["direction"].shape), g["direction"])
+    # camera rays: the oracle's Camera::ray at jitter 0 must reproduce the fixture's directions bitwise
+    w = h = dim
+    for i in (0, 1, dim, dim * dim // 2 + 7, dim * dim - 1):
+        x, y = i % w, i // w
+        sx = 2.0 * ((x + 0.5) / w) - 1.0
+        sy = 1.0 - 2.0 * ((y + 0.5) / h)
+        r = O.camera_ray(data.camera, sx, sy, 2.0 / w, 2.0 / h)
+        assert r[1].tobytes() == g["direction"][i].tobytes()
+    for use_bvh in (False, True):
+        tri, t = oracle.trace_closest(rays, use_bvh=use_bvh)
+        assert np.array_equal(tri, g["tri"])
+        assert t.tobytes() == g["t"].tobytes()
+
+
+# ---- K1 / K2 --------------------------------------------------------------------------------------
+def test_k1_cornell_box_obj_is_black():
+    oracle = O.OracleScene(pt.scene_data("cornell_box"))
+    assert not oracle.render(pt.Config(dim=32, samples_pr_pixel=2)).any()
+
+
+def test_k2_furnace():
+    from test_gpu_parity import furnace
+    rho, E, B = 0.5, 2.0, 3
+    img = O.OracleScene(furnace(rho, E)).render(pt.Config(dim=24, samples_pr_pixel=2, bounces=B)) / 2
+    assert np.allclose(img, E * sum(rho ** k for k in range(B + 1)), rtol=1e-12, atol=0)
+
+
+# ---- K4 camera ------------------------------------------------------------------------------------
+def test_k4_camera():
+    cam = pt.CAMERAS["Test"]
+    r = O.camera_ray(cam, 0.0, 0.0, 0.01, 0.01)
+    assert np.array_equal(r[0], [275.0, 275.0, -600.0])
+    assert np.array_equal(r[1], [0.0, 0.0, 1.0])        # (0,0) looks down the view direction
+    assert np.array_equal(r[2], r[0]) and np.array_equal(r[4], r[0])  # differential origins = eye
+    # corners: normalize(2 v + x a0 + y a1); a0 = -(v x up)^ = (+1,0,0), a1 = -(a0 x v)^ = (0,+1,0)
+    for sx in (-1.0, 1.0):
+        for sy in (-1.0, 1.0):
+            d = O.camera_ray(cam, sx, sy, 0.0, 0.0)[1]
+            e = np.array([sx, sy, 2.0]) / np.sqrt(6.0)
+            assert np.allclose(d, e, rtol=0, atol=1e-15)
+    nd = O.camera_ray(cam, 0.3, 0.2, 0.01, 0.01, use_diffs=False)
+    assert not nd[2:].any()                              # --no-diffs leaves the differentials zero
+
+
+# ---- K5 Lambertian ----------------------------------------------------------------------------------
+def test_k5_lambertian():
+    rng = np.random.default_rng(1)
+    rho = np.array([0.9, 0.5, 0.1])
+    cos_sum = 0.0
+    for _ in range(2000):
+        n = O.normalize(rng.normal(size=3))
+        xi1, xi2 = rng.random(2)
+        f, wi, pdf = O.lambertian_sample(rho, n, xi1, xi2)
+        c = float(np.dot(wi, n))
+        assert c >= -1e-15 and abs(np.linalg.norm(wi) - 1.0) < 1e-14
+        assert np.allclose(f * abs(c) / pdf, rho, rtol=1e-14)       # f |cos| / pdf == rho
+        assert np.allclose(f, rho / math.pi, rtol=1e-15) and abs(pdf - c / math.pi) < 1e-15
+        cos_sum += c
+    assert abs(cos_sum / 2000 - 2.0 / 3.0) < 0.02                    # E[cos] = 2/3
+    # vec3.rs:156 signum(-0.0) = -1: the two poles give mirrored frames, both valid
+    for nz in (1.0, -1.0):
+        w = O.rotate_to((0.0, 0.0, 1.0), (0.0, 0.0, nz))
+        assert np.array_equal(w, [0.0, 0.0, nz])
+
+
+# ---- K6 Beckmann / conductor -------------------------------------------------------------------------
+def test_k6_beckmann_and_conductor():
+    n = (0.0, 0.0, 1.0)
+    for alpha in (0.3, 0.1):
+        th = np.linspace(0.0, math.pi / 2, 20001)[:-1]
+        D = np.array([O.beckmann_D(alpha, (math.sin(t), 0.0, math.cos(t)), n) for t in th])
+        integ = np.trapezoid(D * np.cos(th) * np.sin(th), th) * 2 * math.pi
+        assert abs(integ - 1.0) < 2e-3                                # int D (h.n) dw = 1
+    assert O.beckmann_D(0.3, (0.0, 0.0, -1.0), n) == 0.0
+    # G1 = 1 for a = 1/(alpha tan) >= 1.6, rational fit below, 0 on the wrong side
+    w = (math.sin(0.2), 0.0, math.cos(0.2))
+    assert O.beckmann_G1(0.3, w, n, n) == 1.0
+    w = (math.sin(1.4), 0.0, math.cos(1.4))
+    a = 1.0 / (0.3 * math.tan(math.acos(w[2])))
+    assert a < 1.6
+    assert abs(O.beckmann_G1(0.3, w, n, n) - (3.535 * a + 2.181 * a * a) / (1 + 2.276 * a + 2.577 * a * a)) < 1e-12
+    assert O.beckmann_G1(0.3, (0.6, 0.0, 0.8), (-1.0, 0.0, 0.0), n) == 0.0   # (w.m)/(w.n) <= 0
+    assert O.beckmann_G1(0.3, (0.0, 0.0, -1.0), n, n) > 0.0   # quirk: both dots negative passes the test
+    # microfacet.rs:45,265-266: eta = 1/32, etak = 0.1/32; normal incidence ((eta-1)^2+k^2)/((eta+1)^2+k^2)
+    eta, k = 1 / 32, 0.1 / 32
+    expect = ((eta - 1) ** 2 + k * k) / ((eta + 1) ** 2 + k * k)
+    got = O.conductor(1.0)
+    assert np.allclose(got, expect, rtol=1e-12) and abs(expect - 0.88246) < 1e-4
+    assert got[0] == got[1] == got[2]
+
+
+def test_glossy_sample_consistency():
+    rng = np.random.default_rng(3)
+    n = np.array([0.0, 0.0, 1.0])
+    for alpha in (0.3, 0.05):
+        for _ in range(200):
+            wo = O.normalize(rng.normal(size=3) * [1, 1, 0.3] + [0, 0, 1.0])
+            f, wi, pdf = O.glossy_sample((1.0, 1.0, 1.0), alpha, -wo, n, *rng.random(2))
+            assert abs(np.linalg.norm(wi) - 1) < 1e-12
+            h = O.normalize(wo + wi)
+            assert abs(np.dot(h, wo) - np.dot(h, wi)) < 1e-12       # mirror reflection about h
+            assert f[0] == f[1] == f[2] and f[0] >= 0.0
+            if pdf <= 0.0:
+                # quirk: the sampled half vector faced away from wo, so
+                # pdf = D |h.n| / (4 wo.h) is negative and normalize(wo + wi) is -h_sampled
+                assert h[2] < 0.0
+                continue
+            expect_pdf = O.beckmann_D(alpha, h, n) * abs(h[2]) / (4 * np.dot(wo, h))
+            assert abs(pdf - expect_pdf) <= 1e-9 * abs(expect_pdf)
+
+
+def test_sample_sphere_is_unit():
+    rng = np.random.default_rng(0)
+    for _ in range(100):
+        p = O.sample_sphere(*rng.random(2))
+        assert abs(np.linalg.norm(p) - 1.0) < 1e-12
+
+
+# ---- K7 mipmap -----------------------------------------------------------------------------------------
+def tex_scene(img):
+    verts = np.array([[0, 0, 1], [1, 0, 1], [0, 1, 1]], np.float32)
+    mats = np.zeros(1, pt.MATERIAL_DTYPE)
+    mats["tex"] = 0
+    return pt.SceneData(verts, [[0, 1, 2]], [0], mats, textures=[img])
+
+
+def test_k7_mipmap():
+    const = np.full((8, 8, 3), 51, np.uint8)
+    const[..., 1] = 102
+    o = O.OracleScene(tex_scene(const))
+    assert o.texture_levels(0) == 4
+    rng = np.random.default_rng(0)
+    uv = rng.random((64, 2))
+    for width in (0.0, 1e-3, 0.2, 0.6, 5.0):
+        rgb = o.texture_lookup(0, uv, np.full((64, 2), width), np.zeros((64, 2)))
+        assert np.allclose(rgb, [0.2, 0.4, 0.2], rtol=0, atol=1e-15)
+    # 2x2: pyramid top = mean; row flip: Image[0] is the LAST data row (mipmap.rs:52-55)
+    img = np.array([[[10, 0, 0], [20, 0, 0]], [[30, 0, 0], [40, 0, 0]]], np.uint8)
+    o = O.OracleScene(tex_scene(img))
+    assert o.texture_levels(0) == 2
+    assert abs(o.texture_texel(0, 1, 0)[0] - (10 + 20 + 30 + 40) / 4 / 255) < 1e-16
+    # u,v = texel centres of level 0, no footprint -> level 0 bilinear hits exact texels
+    # t = 0 is the image bottom: (u=.25,v=.25) -> data row 1 (bottom row), column 0 = 30
+    rgb = o.texture_lookup(0, [[0.25, 0.25], [0.75, 0.25], [0.25, 0.75], [0.75, 0.75]], np.zeros((4, 2)), np.zeros((4, 2)))
+    assert np.allclose(rgb[:, 0] * 255, [30, 40, 10, 20], rtol=0, atol=1e-12)
+    # level >= n_levels - 1 -> the 1x1 texel
+    rgb = o.texture_lookup(0, [[0.1, 0.9]], [[1.0, 0.0]], [[0.0, 0.0]])
+    assert abs(rgb[0, 0] - 25 / 255) < 1e-16
+    # negative ds extrapolation quirk (mipmap.rs:106-109): u < half a texel saturates s0 at 0
+    rgb = o.texture_lookup(0, [[0.0, 0.25]], [[0.0, 0.0]], [[0.0, 0.0]])
+    ds = 0.0 * 2 - 0.5
+    assert abs(rgb[0, 0] * 255 - ((1 - ds) * 30 + ds * 40)) < 1e-12
+    with pytest.raises(RuntimeError):
+        O.OracleScene(tex_scene(np.zeros((6, 6, 3), np.uint8)))     # mipmap.rs:86-89 panics
+
+
+# ---- K8 quantise / PPM -----------------------------------------------------------------------------------
+def test_k8_quantise_and_ppm(tmp_path):
+    q = O.lib.orc_f64_to_8bit_color
+    assert q(1.0) == 255 and q(0.5) == 128 and q(-3.0) == 0 and q(7.0) == 255 and q(0.0) == 0
+    assert q(float("nan")) == 0
+    acc = np.array([[[2.0, 1.0, 0.0], [0.5, 4.0, -1.0]]])
+    rgb = np.zeros((1, 2, 3), np.uint8)
+    O.lib.orc_resolve_rgb8(acc.ctypes.data_as(O._dp), 2, 2, rgb.ctypes.data_as(O._P(O.C.c_uint8)))
+    assert rgb.tolist() == [[[255, 128, 0], [64, 255, 0]]]
+    path = tmp_path / "o.ppm"
+    O.lib.orc_write_ppm(os.fsencode(str(path)), 2, 1, rgb.ctypes.data_as(O._P(O.C.c_uint8)))
+    assert path.read_text() == "P3\n2 1\n255\n255 128 0\n64 255 0\n"
+
+
+# ---- render-level sanity -----------------------------------------------------------------------------------
+def test_oracle_threads_and_bvh_do_not_change_the_image():
+    o = O.OracleScene(pt.scene_data("CornellBox"))
+    cfg = pt.Config(dim=48, samples_pr_pixel=3, seed=5)
+    a = o.render(cfg, threads=1, use_bvh=False)
+    b = o.render(cfg, threads=4, use_bvh=True)
+    assert a.tobytes() == b.tobytes()
+    assert a.mean() > 0.1 and np.isfinite(a).all()
+
+
+def test_nee_converges_to_the_same_image():
+    # NEE (+MIS) is an addition; criterion: same converged image as render()
+    o = O.OracleScene(pt.scene_data("CornellBox"))
+    naive = o.render(pt.Config(dim=16, samples_pr_pixel=1500, seed=1)) / 1500
+    nee = o.render(pt.Config(dim=16, samples_pr_pixel=300, seed=2, nee=True)) / 300
+    rel = abs(nee.mean() - naive.mean()) / naive.mean()
+    assert rel < 0.03, rel
+    # per-channel block means (4x4 blocks) agree within Monte-Carlo noise
+    bn = naive.reshape(4, 4, 4, 4, 3).mean(axis=(1, 3))
+    be = nee.reshape(4, 4, 4, 4, 3).mean(axis=(1, 3))
+    assert np.abs(be - bn).max() < 0.15 * bn.max()
