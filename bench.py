@@ -34,7 +34,8 @@ def main():
     ap.add_argument("--spp", type=int, default=8, help="frames per step")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--scene", default="CornellBox")
+    ap.add_argument("--scene", default="CornellBox", help="models/<scene>.obj, or 'heightfield' (SURVEY config 5)")
+    ap.add_argument("--cells", type=int, default=2236, help="heightfield resolution (2236 -> 9,999,392 triangles)")
     ap.add_argument("--bounces", type=int, default=2)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     args = ap.parse_args()
@@ -56,7 +57,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    data = pt.scene_data(args.scene)
+    if args.scene == "heightfield":
+        from pathtracer_amd.synthetic import heightfield_box
+        data = heightfield_box(args.cells)
+    else:
+        data = pt.scene_data(args.scene)
     scene = pt.Scene(data, device=local_rank)
     cfg = pt.Config(width=args.width, height=args.height, bounces=args.bounces, seed=1, spp_per_batch=args.spp)
     accum = torch.zeros((args.height, args.width, 3), dtype=torch.float64, device=dev)
@@ -176,9 +181,12 @@ def main():
             "metric": "Msamples/s", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": n_gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "reference scene models/CornellBox.obj, counter-based RNG (no dataset)",
-            "config": {"workload": f"{args.scene}.obj {args.width}x{args.height} bounces={args.bounces}, "
-                                   f"{args.spp} spp per step per GPU (BASELINE.json configs[1])",
+            "data": (f"synthetic heightfield box, {data.n_tris} triangles, seed 12345" if args.scene == "heightfield"
+                     else f"reference scene models/{args.scene}.obj") + ", counter-based RNG (no dataset)",
+            "config": {"workload": f"{args.scene}{'' if args.scene == 'heightfield' else '.obj'} {args.width}x{args.height} "
+                                   f"bounces={args.bounces}, {args.spp} spp per step per GPU"
+                                   + (" (BASELINE.json configs[1])" if args.scene == "CornellBox" else ""),
+                       "triangles": data.n_tris,
                        "partitioning": "sample ranges + one RCCL reduce" if world > 1 else "single GPU",
                        "samples_per_step": npix * args.spp * world},
             "mrays_per_s": round(total_rays / dt / 1e6, 3),

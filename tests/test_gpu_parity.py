@@ -182,3 +182,47 @@ def test_k2_furnace(gpu):
     img = scene.render(cfg) / 2
     expect = E * sum(rho ** k for k in range(B + 1))
     assert np.allclose(img, expect, rtol=1e-12, atol=0)
+
+
+# ---- large synthetic scene (SURVEY config 5 generator) --------------------------------------------
+def test_heightfield_hits_bit_exact(gpu):
+    from pathtracer_amd.synthetic import heightfield_box
+    data = heightfield_box(cells=200)          # 80,010 triangles, deep BVH, real leaves
+    scene, oracle = pt.Scene(data, gpu), O.OracleScene(data)
+    nodes, order, depth = scene.bvh()
+    assert depth <= 32 and sorted(order.tolist()) == list(range(data.n_tris))
+    cfg = pt.Config(dim=160, seed=2)
+    rays = scene.generate_rays(cfg, 0)
+    tri, t = scene.trace_closest(rays)
+    rtri, rt = oracle.trace_closest(rays, use_bvh=True)   # oracle BVH == oracle brute force (CPU test)
+    assert np.array_equal(tri, rtri) and np.array_equal(bits(t), bits(rt))
+    rays = random_rays(data, 30000, seed=3)
+    tri, t = scene.trace_closest(rays)
+    rtri, rt = oracle.trace_closest(rays, use_bvh=True)
+    assert np.array_equal(tri, rtri) and np.array_equal(bits(t), bits(rt))
+    sub = slice(0, 300)                                   # and a brute-force slice, no BVH on either side
+    btri, bt = oracle.trace_closest(rays[sub], use_bvh=False)
+    assert np.array_equal(tri[sub], btri) and np.array_equal(bits(t[sub]), bits(bt))
+    img = scene.render(pt.Config(dim=64, samples_pr_pixel=3, seed=1))
+    ref = oracle.render(pt.Config(dim=64, samples_pr_pixel=3, seed=1), use_bvh=True)
+    assert (np.abs(img - ref) > 1e-9 * np.maximum(1.0, np.abs(ref))).mean() < 2e-3
+
+
+def test_caller_supplied_bvh_and_validation(gpu):
+    data = pt.scene_data("CornellBox")
+    nodes, order, depth = pt.bvh_build(data.verts, data.tris, max_leaf=2)
+    data.bvh_nodes, data.bvh_tri_order = nodes, order
+    scene, oracle = pt.Scene(data, gpu), O.OracleScene(pt.scene_data("CornellBox"))
+    rays = random_rays(data, 5000, seed=1)
+    tri, t = scene.trace_closest(rays)
+    rtri, rt = oracle.trace_closest(rays)
+    assert np.array_equal(tri, rtri) and np.array_equal(bits(t), bits(rt))
+    bad = pt.scene_data("CornellBox")
+    bad.bvh_nodes, bad.bvh_tri_order = nodes.copy(), order.copy()
+    bad.bvh_nodes["child"][0, 0] = 10_000              # out-of-range child must be refused, not traversed
+    with pytest.raises(pt.PtError):
+        pt.Scene(bad, gpu)
+    bad.bvh_nodes = nodes.copy()
+    bad.bvh_tri_order = np.zeros_like(order)           # duplicate triangle ids
+    with pytest.raises(pt.PtError):
+        pt.Scene(bad, gpu)
