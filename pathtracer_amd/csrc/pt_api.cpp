@@ -420,6 +420,7 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
     dv.n_nodes = d->n_tris ? (uint32_t)s->nodes.size() : 0u;
     dv.n_tris = d->n_tris;
     dv.n_lights = (uint32_t)lights.size();
+    dv.bvh_depth = s->depth;
     dv.light_area = acc;
     // scene.rs:38-42, hoisted out of Camera::ray
     H3 view{d->camera.view[0], d->camera.view[1], d->camera.view[2]};

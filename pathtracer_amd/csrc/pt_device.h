@@ -53,7 +53,7 @@ struct Scene {
     const Material* mats;
     const Texture* texs;
     const Light* lights;
-    uint32_t n_nodes, n_tris, n_lights, pad;
+    uint32_t n_nodes, n_tris, n_lights, bvh_depth;
     double light_area;
     Camera cam;
     double background[3];

@@ -116,11 +116,22 @@ __device__ __forceinline__ bool tri_test(const TriV& tr, D3 o, D3 d, double t_mi
     if (fabs(dn) < 1.0e-12) return false;
     D3 vo = tr.v0 - o;
     D3 tmp = cross(vo, d);
+    double a = dot(tmp, e1), b = dot(tmp, e0), num = dot(vo, normal);
+    // Division-free exact rejects.  With |x| >= 2^-500 and 1e-12 <= |dn| <= 2^500 neither
+    // x * (1/dn) nor x / dn can round to zero, so their sign is sign(x) * sign(dn): the reference's
+    // `v < 0`, `w < 0` and (for t_min >= 0) `t < t_min` are decided without dividing.  NaNs and
+    // out-of-range magnitudes fail the guards and take the full path below.
+    if (fabs(dn) <= 0x1p500) {
+        bool dneg = dn < 0.;
+        if (fabs(a) >= 0x1p-500 && (a < 0.) != dneg) return false;                  // v < 0
+        if (fabs(b) >= 0x1p-500 && (b < 0.) != dneg) return false;                  // w < 0
+        if (t_min >= 0. && fabs(num) >= 0x1p-500 && (num < 0.) != dneg) return false;  // t < 0 <= t_min
+    }
     double denom = 1. / dn;
-    double v = dot(tmp, e1) * denom;
-    double w = dot(tmp, e0) * denom;
+    double v = a * denom;
+    double w = b * denom;
     if (v < 0.0 || w < 0.0 || v + w > 1.0) return false;
-    double t = dot(vo, normal) / dn;
+    double t = num / dn;
     if (t < t_min || t > t_max) return false;
     t_out = t; v_out = v; w_out = w;
     return true;
@@ -142,7 +153,7 @@ __device__ __forceinline__ bool slab(double lox, double loy, double loz, double 
 
 // BVH traversal, one ray per lane, stack in LDS laid out [entry][lane] (bank = lane: conflict-free).
 // ANY = stop at the first accepted triangle (shadow rays).  Returns leaf-order index / PT_MISS.
-template <bool ANY, bool STATS>
+template <int DEPTH, bool ANY, bool STATS>
 __device__ __forceinline__ uint32_t traverse(const Scene& sc, D3 o, D3 d, double t_min, double& t_max, int* stk,
                                              uint32_t& n_nodes, uint32_t& n_tris) {
     uint32_t best = PT_MISS, best_id = PT_MISS;
@@ -164,7 +175,7 @@ __device__ __forceinline__ uint32_t traverse(const Scene& sc, D3 o, D3 d, double
             if (h0 && h1) {
                 int nearc = c0, farc = c1;
                 if (tn1 < tn0) { nearc = c1; farc = c0; }
-                if (sp < kStackDepth) { stk[sp * kBlock] = farc; ++sp; }
+                if (sp < DEPTH) { stk[sp * kBlock] = farc; ++sp; }
                 cur = nearc;
                 continue;
             } else if (h0) {
@@ -207,23 +218,27 @@ __device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t nb) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
 }
 
-template <bool STATS>
+template <int DEPTH, bool STATS>
 __global__ __launch_bounds__(kBlock) void k_extend(Scene sc, Queue q, const double* __restrict__ tmin,
                                                    const double* __restrict__ tmax,
                                                    const uint32_t* __restrict__ count, uint32_t n_max, Hits hits,
                                                    Counters* ctr) {
-    __shared__ int stack[kStackDepth * kBlock];
+    __shared__ int stack[DEPTH * kBlock];
     uint32_t n = count ? min(*count, n_max) : n_max;
-    uint32_t blk = xcd_block(blockIdx.x, gridDim.x);
-    uint32_t i = blk * kBlock + threadIdx.x;
     if (ctr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->rays, (unsigned long long)n);
+    // the grid is sized for n_max; only the first ceil(n / kBlock) blocks have work, and those are
+    // the ones spread over the XCDs (remapping over gridDim would leave whole XCDs idle when n < n_max)
+    uint32_t nb_live = (n + kBlock - 1) / kBlock;
+    if (blockIdx.x >= nb_live) return;
+    uint32_t blk = xcd_block(blockIdx.x, nb_live);
+    uint32_t i = blk * kBlock + threadIdx.x;
     if (i >= n) return;
     D3 o = mk(q.o[0][i], q.o[1][i], q.o[2][i]);
     D3 d = mk(q.d[0][i], q.d[1][i], q.d[2][i]);
     double t_min = tmin ? tmin[i] : 1e-5;                     // ray.rs:21
     double t_max = tmax ? tmax[i] : 1.7976931348623157e308;   // ray.rs:22 f64::MAX
     uint32_t nn = 0, nt = 0;
-    uint32_t tri = traverse<false, STATS>(sc, o, d, t_min, t_max, stack + threadIdx.x, nn, nt);
+    uint32_t tri = traverse<DEPTH, false, STATS>(sc, o, d, t_min, t_max, stack + threadIdx.x, nn, nt);
     hits.tri[i] = tri;
     hits.t[i] = t_max;
     if (STATS) {
@@ -239,18 +254,21 @@ __global__ __launch_bounds__(kBlock) void k_extend(Scene sc, Queue q, const doub
     }
 }
 
+template <int DEPTH>
 __global__ __launch_bounds__(kBlock) void k_shadow(Scene sc, ShadowQueue sq, const uint32_t* __restrict__ count,
                                                    uint32_t n_max, Sample3 ls, Counters* ctr) {
-    __shared__ int stack[kStackDepth * kBlock];
+    __shared__ int stack[DEPTH * kBlock];
     uint32_t n = min(*count, n_max);
-    uint32_t i = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
     if (ctr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->shadow_rays, (unsigned long long)n);
+    uint32_t nb_live = (n + kBlock - 1) / kBlock;
+    if (blockIdx.x >= nb_live) return;
+    uint32_t i = xcd_block(blockIdx.x, nb_live) * kBlock + threadIdx.x;
     if (i >= n) return;
     D3 o = mk(sq.o[0][i], sq.o[1][i], sq.o[2][i]);
     D3 d = mk(sq.d[0][i], sq.d[1][i], sq.d[2][i]);
     double t_max = sq.tmax[i];
     uint32_t nn = 0, nt = 0;
-    uint32_t tri = traverse<true, false>(sc, o, d, 1e-5, t_max, stack + threadIdx.x, nn, nt);
+    uint32_t tri = traverse<DEPTH, true, false>(sc, o, d, 1e-5, t_max, stack + threadIdx.x, nn, nt);
     if (tri == PT_MISS) {
         uint32_t slot = sq.slot[i];
         ls.c[0][slot] += sq.c[0][i];
@@ -771,13 +789,21 @@ void launch_generate_rays(const Scene& sc, const Frame& fr, double* rays_out, hi
     if (!fr.n_tile_pixels) return;
     hipLaunchKernelGGL(k_generate_rays, dim3(blocks_for(fr.n_tile_pixels)), dim3(kBlock), 0, st, sc, fr, rays_out);
 }
+// The LDS stack is sized for the scene's BVH depth: 8 / 16 / 32 entries per lane (8 / 16 / 32 KB per
+// block), so shallow trees do not pay occupancy for stack they cannot use.
+template <bool STATS>
+static void launch_extend_t(const Scene& sc, Queue q, const double* tmin, const double* tmax, const uint32_t* count,
+                            uint32_t n_max, Hits hits, Counters* ctr, hipStream_t st) {
+    dim3 g(blocks_for(n_max)), b(kBlock);
+    if (sc.bvh_depth <= 8) hipLaunchKernelGGL((k_extend<8, STATS>), g, b, 0, st, sc, q, tmin, tmax, count, n_max, hits, ctr);
+    else if (sc.bvh_depth <= 16) hipLaunchKernelGGL((k_extend<16, STATS>), g, b, 0, st, sc, q, tmin, tmax, count, n_max, hits, ctr);
+    else hipLaunchKernelGGL((k_extend<32, STATS>), g, b, 0, st, sc, q, tmin, tmax, count, n_max, hits, ctr);
+}
 void launch_extend(const Scene& sc, Queue q, const double* tmin, const double* tmax, const uint32_t* count,
                    uint32_t n_max, Hits hits, Counters* ctr, bool stats, hipStream_t st) {
     if (!n_max) return;
-    if (stats)
-        hipLaunchKernelGGL(k_extend<true>, dim3(blocks_for(n_max)), dim3(kBlock), 0, st, sc, q, tmin, tmax, count, n_max, hits, ctr);
-    else
-        hipLaunchKernelGGL(k_extend<false>, dim3(blocks_for(n_max)), dim3(kBlock), 0, st, sc, q, tmin, tmax, count, n_max, hits, ctr);
+    if (stats) launch_extend_t<true>(sc, q, tmin, tmax, count, n_max, hits, ctr, st);
+    else launch_extend_t<false>(sc, q, tmin, tmax, count, n_max, hits, ctr, st);
 }
 void launch_shade(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, Hits hits, const uint32_t* count,
                   uint32_t n_max, Queue out, uint32_t* out_count, ShadowQueue sq, uint32_t* sq_count, Sample3 ls,
@@ -796,7 +822,10 @@ void launch_shade(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, H
 void launch_shadow(const Scene& sc, ShadowQueue sq, const uint32_t* count, uint32_t n_max, Sample3 ls, Counters* ctr,
                    hipStream_t st) {
     if (!n_max) return;
-    hipLaunchKernelGGL(k_shadow, dim3(blocks_for(n_max)), dim3(kBlock), 0, st, sc, sq, count, n_max, ls, ctr);
+    dim3 g(blocks_for(n_max)), b(kBlock);
+    if (sc.bvh_depth <= 8) hipLaunchKernelGGL(k_shadow<8>, g, b, 0, st, sc, sq, count, n_max, ls, ctr);
+    else if (sc.bvh_depth <= 16) hipLaunchKernelGGL(k_shadow<16>, g, b, 0, st, sc, sq, count, n_max, ls, ctr);
+    else hipLaunchKernelGGL(k_shadow<32>, g, b, 0, st, sc, sq, count, n_max, ls, ctr);
 }
 void launch_accumulate(const Frame& fr, Sample3 ls, double* accum, hipStream_t st) {
     if (!fr.n_tile_pixels) return;
