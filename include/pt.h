@@ -136,6 +136,7 @@ typedef struct pt_kernel_stat {
     double ms; /* summed HIP-event time */
 } pt_kernel_stat;
 
+/* PT_K_GENERATE stays 0 in renders: the stage is fused into the bounce-0 extend/shade kernels */
 enum { PT_K_GENERATE = 0, PT_K_EXTEND, PT_K_SHADE, PT_K_SHADOW, PT_K_ACCUMULATE, PT_K_COUNT };
 
 typedef struct pt_stats {

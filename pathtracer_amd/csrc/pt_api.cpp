@@ -533,17 +533,16 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
         fr.jitter = w.jitter.as<double>() + (size_t)b0 * 2;
         const uint32_t n_max = ns * npix;
         HIP_TRY(hipMemsetAsync(w.counters, 0, kCounterWords * sizeof(uint32_t), st));
-        {
-            Timer t(s, st, PT_K_GENERATE);
-            ptd::launch_generate(s->dev, fr, w.q[0], st);
-        }
+        // the generate stage is fused into the bounce-0 extend and shade kernels (they rebuild the
+        // camera ray from the pixel): no primary-ray queue is written or read.
         for (uint32_t bounce = 0; bounce <= P->max_bounces; ++bounce) {
             const uint32_t* cnt = bounce == 0 ? nullptr : w.counters + bounce;
             ptd::Queue& qin = w.q[bounce & 1];
             ptd::Queue& qout = w.q[(bounce + 1) & 1];
             {
                 Timer t(s, st, PT_K_EXTEND);
-                ptd::launch_extend(s->dev, qin, nullptr, nullptr, cnt, n_max, w.hits, ctr, stats, st);
+                if (bounce == 0) ptd::launch_extend_primary(s->dev, fr, w.hits, ctr, stats, st);
+                else ptd::launch_extend(s->dev, qin, nullptr, nullptr, cnt, n_max, w.hits, ctr, stats, st);
             }
             {
                 Timer t(s, st, PT_K_SHADE);

@@ -105,11 +105,11 @@ constexpr int kStackDepth = 32;  // LDS traversal stack entries per lane; builde
 constexpr int kBlock = 256;
 
 // ---- launchers (pt_kernels.hip) ---------------------------------------------------------------
-void launch_generate(const Scene& sc, const Frame& fr, Queue q, hipStream_t st);
 void launch_generate_rays(const Scene& sc, const Frame& fr, double* rays_out /* pt_ray[n] */, hipStream_t st);
 // count == nullptr -> n_max rays are live
 void launch_extend(const Scene& sc, Queue q, const double* tmin, const double* tmax, const uint32_t* count,
                    uint32_t n_max, Hits hits, Counters* ctr, bool stats, hipStream_t st);
+void launch_extend_primary(const Scene& sc, const Frame& fr, Hits hits, Counters* ctr, bool stats, hipStream_t st);
 void launch_shade(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, Hits hits, const uint32_t* count,
                   uint32_t n_max, Queue out, uint32_t* out_count, ShadowQueue sq, uint32_t* sq_count,
                   Sample3 lsample, hipStream_t st);

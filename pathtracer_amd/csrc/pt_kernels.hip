@@ -218,8 +218,10 @@ __device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t nb) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
 }
 
-template <int DEPTH, bool STATS>
-__global__ __launch_bounds__(kBlock) void k_extend(Scene sc, Queue q, const double* __restrict__ tmin,
+// PRIMARY: the generate stage (main.rs:412-427 + scene.rs:37-45) runs in the prologue — lane i is
+// path slot i of the batch and builds its camera ray in registers; nothing is read from the queue.
+template <int DEPTH, bool STATS, bool PRIMARY>
+__global__ __launch_bounds__(kBlock) void k_extend(Scene sc, Frame fr, Queue q, const double* __restrict__ tmin,
                                                    const double* __restrict__ tmax,
                                                    const uint32_t* __restrict__ count, uint32_t n_max, Hits hits,
                                                    Counters* ctr) {
@@ -233,8 +235,17 @@ __global__ __launch_bounds__(kBlock) void k_extend(Scene sc, Queue q, const doub
     uint32_t blk = xcd_block(blockIdx.x, nb_live);
     uint32_t i = blk * kBlock + threadIdx.x;
     if (i >= n) return;
-    D3 o = mk(q.o[0][i], q.o[1][i], q.o[2][i]);
-    D3 d = mk(q.d[0][i], q.d[1][i], q.d[2][i]);
+    D3 o, d;
+    if (PRIMARY) {
+        uint32_t s = i / fr.n_tile_pixels, p = i - s * fr.n_tile_pixels;
+        uint32_t ty = p / fr.tile_w, tx = p - ty * fr.tile_w;
+        PixelArgs a = pixel_args(fr.x0 + tx, fr.y0 + ty, fr.width, fr.height, fr.jitter[2 * s], fr.jitter[2 * s + 1]);
+        o = ld3(sc.cam.eye);
+        d = camera_dir(sc.cam, a.x, a.y);
+    } else {
+        o = mk(q.o[0][i], q.o[1][i], q.o[2][i]);
+        d = mk(q.d[0][i], q.d[1][i], q.d[2][i]);
+    }
     double t_min = tmin ? tmin[i] : 1e-5;                     // ray.rs:21
     double t_max = tmax ? tmax[i] : 1.7976931348623157e308;   // ray.rs:22 f64::MAX
     uint32_t nn = 0, nt = 0;
@@ -278,19 +289,8 @@ __global__ __launch_bounds__(kBlock) void k_shadow(Scene sc, ShadowQueue sq, con
 }
 
 // ------------------------------------------------------------------------------------------------
-// generate
-__global__ __launch_bounds__(kBlock) void k_generate(Scene sc, Frame fr, Queue q) {
-    uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
-    uint32_t n = fr.n_tile_pixels * fr.n_samples;
-    if (slot >= n) return;
-    uint32_t s = slot / fr.n_tile_pixels, p = slot - s * fr.n_tile_pixels;
-    uint32_t ty = p / fr.tile_w, tx = p - ty * fr.tile_w;
-    PixelArgs a = pixel_args(fr.x0 + tx, fr.y0 + ty, fr.width, fr.height, fr.jitter[2 * s], fr.jitter[2 * s + 1]);
-    D3 dir = camera_dir(sc.cam, a.x, a.y);
-    q.o[0][slot] = sc.cam.eye[0]; q.o[1][slot] = sc.cam.eye[1]; q.o[2][slot] = sc.cam.eye[2];
-    q.d[0][slot] = dir.x; q.d[1][slot] = dir.y; q.d[2][slot] = dir.z;
-}
-
+// generate — in the render path this stage is fused into the prologue of the bounce-0 extend and
+// shade kernels (PRIMARY / FIRST); standalone it exists as the parity entry below.
 // parity entry: the same rays as AoS pt_ray records (frame fr.sample_base, n_samples == 1)
 __global__ __launch_bounds__(kBlock) void k_generate_rays(Scene sc, Frame fr, double* __restrict__ rays) {
     uint32_t p = blockIdx.x * kBlock + threadIdx.x;
@@ -559,8 +559,13 @@ __device__ __forceinline__ uint32_t compact_slot(bool alive, uint32_t* counter, 
     return pos;
 }
 
-// shade: one lane per live path.  FIRST = bounce 0 (queue index == slot, throughput == 1).
-template <bool FIRST, bool NEE>
+// shade: one lane per live path.
+//   FIRST = bounce 0: queue index == slot, throughput == 1, and the camera ray is recomputed from
+//           the pixel (same arithmetic as the generate stage) instead of being read back from HBM.
+//   LAST  = bounce == max_bounces: only main.rs:299/307 remain (the reference still samples the
+//           BRDF there, main.rs:310, but nothing consumes it), so the ray and hit distance are not
+//           even loaded unless NEE needs them for the MIS weight.
+template <bool FIRST, bool LAST, bool NEE>
 __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t bounce, Queue in, Hits hits,
                                                   const uint32_t* __restrict__ count, uint32_t n_max, Queue out,
                                                   uint32_t* out_count, ShadowQueue sq, uint32_t* sq_count,
@@ -579,13 +584,30 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
     double s_tmax = 0.;
     if (active) {
         slot = FIRST ? i : in.slot[i];
-        D3 o = mk(in.o[0][i], in.o[1][i], in.o[2][i]);
-        D3 d = mk(in.d[0][i], in.d[1][i], in.d[2][i]);
+        uint32_t s = slot / fr.n_tile_pixels, p = slot - s * fr.n_tile_pixels;
+        uint32_t ty = p / fr.tile_w, tx = p - ty * fr.tile_w;
+        uint32_t pixel = (fr.y0 + ty) * fr.width + fr.x0 + tx;
+        uint64_t sample = fr.sample_base + s;
+        constexpr bool kNeedRay = !LAST || NEE;
+        D3 o = mk(0., 0., 0.), d = o;
+        if (FIRST) {
+            PixelArgs a = pixel_args(fr.x0 + tx, fr.y0 + ty, fr.width, fr.height, fr.jitter[2 * s], fr.jitter[2 * s + 1]);
+            o = ld3(sc.cam.eye);
+            d = camera_dir(sc.cam, a.x, a.y);
+        } else if (kNeedRay) {
+            o = mk(in.o[0][i], in.o[1][i], in.o[2][i]);
+            d = mk(in.d[0][i], in.d[1][i], in.d[2][i]);
+        }
         D3 T = FIRST ? mk(1., 1., 1.) : mk(in.T[0][i], in.T[1][i], in.T[2][i]);
         uint32_t leaf = hits.tri[i];
         D3 add;  // what main.rs:299 / :307 adds to color_result
         if (leaf == PT_MISS) {
             add = T * ld3(sc.background);  // main.rs:299
+        } else if (!kNeedRay) {
+            uint32_t mat = (uint32_t)__float_as_int(sc.tris[(size_t)leaf * 3 + 1].w);
+            const Material& m = sc.mats[mat];
+            D3 le = m.kind == PT_MAT_GLOSSY ? mk(0., 0., 0.) : ld3(m.emission);  // microfacet.rs:33-35
+            add = T * le;  // main.rs:307
         } else {
             double t = hits.t[i];
             TriV tr;
@@ -595,10 +617,6 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
             const Material& m = sc.mats[mat];
             D3 le = m.kind == PT_MAT_GLOSSY ? mk(0., 0., 0.) : ld3(m.emission);  // microfacet.rs:33-35
             add = T * le;  // main.rs:307
-            uint32_t s = slot / fr.n_tile_pixels, p = slot - s * fr.n_tile_pixels;
-            uint32_t ty = p / fr.tile_w, tx = p - ty * fr.tile_w;
-            uint32_t pixel = (fr.y0 + ty) * fr.width + fr.x0 + tx;
-            uint64_t sample = fr.sample_base + s;
             if (NEE && !FIRST && (le.x != 0. || le.y != 0. || le.z != 0.)) {
                 // MIS weight of a BRDF-sampled hit on a light (balance heuristic)
                 D3 ln = normalize(cross(tr.v1 - tr.v0, tr.v2 - tr.v0));
@@ -608,7 +626,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
                 double wgt = pp > 0. ? pp / (pp + p_l) : 0.;
                 add = T * le * wgt;
             }
-            if (bounce < fr.max_bounces) {  // the reference also samples at the last hit; the result is unused
+            if (!LAST) {
                 D3 diffuse = mk(0., 0., 0.);
                 if (m.kind != PT_MAT_GLOSSY) diffuse = diffuse_of(sc, m, tr, leaf, o, d, position, normal, fr, FIRST, pixel, s);
                 if (NEE && sc.n_lights) {
@@ -671,7 +689,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
             ls.c[0][slot] += add.x; ls.c[1][slot] += add.y; ls.c[2][slot] += add.z;
         }
     }
-    if (bounce >= fr.max_bounces) return;  // uniform: nothing continues
+    if (LAST) return;  // nothing continues
     uint32_t pos = compact_slot(alive, out_count, lds_a);
     if (alive) {
         out.o[0][pos] = n_o.x; out.o[1][pos] = n_o.y; out.o[2][pos] = n_o.z;
@@ -780,44 +798,52 @@ void launch_jitter(uint64_t seed, uint64_t sample_begin, uint32_t n, double psx,
     if (!n) return;
     hipLaunchKernelGGL(k_jitter, dim3(blocks_for(n)), dim3(kBlock), 0, st, seed, sample_begin, n, psx, psy, out);
 }
-void launch_generate(const Scene& sc, const Frame& fr, Queue q, hipStream_t st) {
-    uint32_t n = fr.n_tile_pixels * fr.n_samples;
-    if (!n) return;
-    hipLaunchKernelGGL(k_generate, dim3(blocks_for(n)), dim3(kBlock), 0, st, sc, fr, q);
-}
 void launch_generate_rays(const Scene& sc, const Frame& fr, double* rays_out, hipStream_t st) {
     if (!fr.n_tile_pixels) return;
     hipLaunchKernelGGL(k_generate_rays, dim3(blocks_for(fr.n_tile_pixels)), dim3(kBlock), 0, st, sc, fr, rays_out);
 }
 // The LDS stack is sized for the scene's BVH depth: 8 / 16 / 32 entries per lane (8 / 16 / 32 KB per
 // block), so shallow trees do not pay occupancy for stack they cannot use.
-template <bool STATS>
-static void launch_extend_t(const Scene& sc, Queue q, const double* tmin, const double* tmax, const uint32_t* count,
-                            uint32_t n_max, Hits hits, Counters* ctr, hipStream_t st) {
+template <bool STATS, bool PRIMARY>
+static void launch_extend_t(const Scene& sc, const Frame& fr, Queue q, const double* tmin, const double* tmax,
+                            const uint32_t* count, uint32_t n_max, Hits hits, Counters* ctr, hipStream_t st) {
     dim3 g(blocks_for(n_max)), b(kBlock);
-    if (sc.bvh_depth <= 8) hipLaunchKernelGGL((k_extend<8, STATS>), g, b, 0, st, sc, q, tmin, tmax, count, n_max, hits, ctr);
-    else if (sc.bvh_depth <= 16) hipLaunchKernelGGL((k_extend<16, STATS>), g, b, 0, st, sc, q, tmin, tmax, count, n_max, hits, ctr);
-    else hipLaunchKernelGGL((k_extend<32, STATS>), g, b, 0, st, sc, q, tmin, tmax, count, n_max, hits, ctr);
+    if (sc.bvh_depth <= 8) hipLaunchKernelGGL((k_extend<8, STATS, PRIMARY>), g, b, 0, st, sc, fr, q, tmin, tmax, count, n_max, hits, ctr);
+    else if (sc.bvh_depth <= 16) hipLaunchKernelGGL((k_extend<16, STATS, PRIMARY>), g, b, 0, st, sc, fr, q, tmin, tmax, count, n_max, hits, ctr);
+    else hipLaunchKernelGGL((k_extend<32, STATS, PRIMARY>), g, b, 0, st, sc, fr, q, tmin, tmax, count, n_max, hits, ctr);
 }
 void launch_extend(const Scene& sc, Queue q, const double* tmin, const double* tmax, const uint32_t* count,
                    uint32_t n_max, Hits hits, Counters* ctr, bool stats, hipStream_t st) {
     if (!n_max) return;
-    if (stats) launch_extend_t<true>(sc, q, tmin, tmax, count, n_max, hits, ctr, st);
-    else launch_extend_t<false>(sc, q, tmin, tmax, count, n_max, hits, ctr, st);
+    Frame fr{};
+    if (stats) launch_extend_t<true, false>(sc, fr, q, tmin, tmax, count, n_max, hits, ctr, st);
+    else launch_extend_t<false, false>(sc, fr, q, tmin, tmax, count, n_max, hits, ctr, st);
+}
+void launch_extend_primary(const Scene& sc, const Frame& fr, Hits hits, Counters* ctr, bool stats, hipStream_t st) {
+    uint32_t n = fr.n_tile_pixels * fr.n_samples;
+    if (!n) return;
+    Queue q{};
+    if (stats) launch_extend_t<true, true>(sc, fr, q, nullptr, nullptr, nullptr, n, hits, ctr, st);
+    else launch_extend_t<false, true>(sc, fr, q, nullptr, nullptr, nullptr, n, hits, ctr, st);
+}
+template <bool FIRST, bool LAST>
+static void launch_shade_t(bool nee, dim3 g, dim3 b, hipStream_t st, const Scene& sc, const Frame& fr, uint32_t bounce,
+                           Queue in, Hits hits, const uint32_t* count, uint32_t n_max, Queue out, uint32_t* out_count,
+                           ShadowQueue sq, uint32_t* sq_count, Sample3 ls) {
+    if (nee) hipLaunchKernelGGL((k_shade<FIRST, LAST, true>), g, b, 0, st, sc, fr, bounce, in, hits, count, n_max, out, out_count, sq, sq_count, ls);
+    else hipLaunchKernelGGL((k_shade<FIRST, LAST, false>), g, b, 0, st, sc, fr, bounce, in, hits, count, n_max, out, out_count, sq, sq_count, ls);
 }
 void launch_shade(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, Hits hits, const uint32_t* count,
                   uint32_t n_max, Queue out, uint32_t* out_count, ShadowQueue sq, uint32_t* sq_count, Sample3 ls,
                   hipStream_t st) {
     if (!n_max) return;
     bool nee = (fr.flags & PT_FLAG_NEE) != 0 && sc.n_lights > 0;
+    bool first = bounce == 0, last = bounce >= fr.max_bounces;
     dim3 g(blocks_for(n_max)), b(kBlock);
-    if (bounce == 0) {
-        if (nee) hipLaunchKernelGGL((k_shade<true, true>), g, b, 0, st, sc, fr, bounce, in, hits, count, n_max, out, out_count, sq, sq_count, ls);
-        else hipLaunchKernelGGL((k_shade<true, false>), g, b, 0, st, sc, fr, bounce, in, hits, count, n_max, out, out_count, sq, sq_count, ls);
-    } else {
-        if (nee) hipLaunchKernelGGL((k_shade<false, true>), g, b, 0, st, sc, fr, bounce, in, hits, count, n_max, out, out_count, sq, sq_count, ls);
-        else hipLaunchKernelGGL((k_shade<false, false>), g, b, 0, st, sc, fr, bounce, in, hits, count, n_max, out, out_count, sq, sq_count, ls);
-    }
+    if (first && last) launch_shade_t<true, true>(nee, g, b, st, sc, fr, bounce, in, hits, count, n_max, out, out_count, sq, sq_count, ls);
+    else if (first) launch_shade_t<true, false>(nee, g, b, st, sc, fr, bounce, in, hits, count, n_max, out, out_count, sq, sq_count, ls);
+    else if (last) launch_shade_t<false, true>(nee, g, b, st, sc, fr, bounce, in, hits, count, n_max, out, out_count, sq, sq_count, ls);
+    else launch_shade_t<false, false>(nee, g, b, st, sc, fr, bounce, in, hits, count, n_max, out, out_count, sq, sq_count, ls);
 }
 void launch_shadow(const Scene& sc, ShadowQueue sq, const uint32_t* count, uint32_t n_max, Sample3 ls, Counters* ctr,
                    hipStream_t st) {

@@ -179,5 +179,5 @@ def test_stats_counters(trio):
     assert st["samples"] <= st["rays"] <= 3 * st["samples"]
     assert st["nodes_visited"] >= 2 * st["rays"] and st["tris_tested"] > st["rays"] // 2
     k = st["kernel"]
-    assert k["extend"]["launches"] == 3 and k["shade"]["launches"] == 3 and k["generate"]["launches"] == 1
+    assert k["extend"]["launches"] == 3 and k["shade"]["launches"] == 3 and k["generate"]["launches"] == 0  # fused into bounce-0 extend/shade
     assert k["extend"]["ms"] > 0
