@@ -153,6 +153,40 @@ __device__ __forceinline__ bool slab(double lox, double loy, double loz, double 
 
 // BVH traversal, one ray per lane, stack in LDS laid out [entry][lane] (bank = lane: conflict-free).
 // ANY = stop at the first accepted triangle (shadow rays).  Returns leaf-order index / PT_MISS.
+// One node step: slab-test both children, pick the next node (near child first, far child pushed)
+// or pop.  kDone marks an empty stack; it is negative like a leaf reference but decodes to a
+// triangle offset >= 2^28, which no scene has.
+constexpr int kDone = (int)0x80000000;
+template <int DEPTH, bool STATS>
+__device__ __forceinline__ int node_step(const Scene& sc, int cur, D3 o, D3 inv, double t_min, double t_max, int* stk,
+                                         int& sp, uint32_t& n_nodes) {
+    const float4* np = sc.nodes + (size_t)cur * 4;
+    float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+    int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+    double tn0, tn1;
+    bool h0 = slab((double)n0.x, (double)n0.y, (double)n0.z, (double)n0.w, (double)n1.x, (double)n1.y, o, inv, t_min,
+                   t_max, tn0) && c0 != PT_BVH_EMPTY;
+    bool h1 = slab((double)n1.z, (double)n1.w, (double)n2.x, (double)n2.y, (double)n2.z, (double)n2.w, o, inv, t_min,
+                   t_max, tn1) && c1 != PT_BVH_EMPTY;
+    if (STATS) n_nodes += 2;
+    if (h0 && h1) {
+        int nearc = c0, farc = c1;
+        if (tn1 < tn0) { nearc = c1; farc = c0; }
+        if (sp < DEPTH) { stk[sp * kBlock] = farc; ++sp; }
+        return nearc;
+    }
+    if (h0) return c0;
+    if (h1) return c1;
+    if (sp == 0) return kDone;
+    --sp;
+    return stk[sp * kBlock];
+}
+
+// BVH traversal, one ray per lane, stack in LDS laid out [entry][lane] (bank = lane: conflict-free).
+// ANY = stop at the first accepted triangle (shadow rays).  Returns leaf-order index / PT_MISS.
+// "while-while" form: the wave keeps stepping through inner nodes until every lane holds a leaf
+// (or is done), then all of them run the expensive triangle tests together; lanes of a wave
+// diverge less than with one node-or-leaf step per iteration.
 template <int DEPTH, bool ANY, bool STATS>
 __device__ __forceinline__ uint32_t traverse(const Scene& sc, D3 o, D3 d, double t_min, double& t_max, int* stk,
                                              uint32_t& n_nodes, uint32_t& n_tris) {
@@ -161,47 +195,24 @@ __device__ __forceinline__ uint32_t traverse(const Scene& sc, D3 o, D3 d, double
     D3 inv = mk(1. / d.x, 1. / d.y, 1. / d.z);
     int sp = 0;
     int cur = 0;
-    for (;;) {
-        if (cur >= 0) {
-            const float4* np = sc.nodes + (size_t)cur * 4;
-            float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-            int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-            double tn0, tn1;
-            bool h0 = slab((double)n0.x, (double)n0.y, (double)n0.z, (double)n0.w, (double)n1.x, (double)n1.y, o, inv,
-                           t_min, t_max, tn0) && c0 != PT_BVH_EMPTY;
-            bool h1 = slab((double)n1.z, (double)n1.w, (double)n2.x, (double)n2.y, (double)n2.z, (double)n2.w, o, inv,
-                           t_min, t_max, tn1) && c1 != PT_BVH_EMPTY;
-            if (STATS) n_nodes += 2;
-            if (h0 && h1) {
-                int nearc = c0, farc = c1;
-                if (tn1 < tn0) { nearc = c1; farc = c0; }
-                if (sp < DEPTH) { stk[sp * kBlock] = farc; ++sp; }
-                cur = nearc;
-                continue;
-            } else if (h0) {
-                cur = c0;
-                continue;
-            } else if (h1) {
-                cur = c1;
-                continue;
-            }
-        } else {
-            int code = ~cur;
-            uint32_t first = (uint32_t)code >> 3, cnt = ((uint32_t)code & 7u) + 1u;
-            for (uint32_t k = 0; k < cnt; ++k) {
-                const float4* tp = sc.tris + (size_t)(first + k) * 3;
-                float4 a = tp[0], b = tp[1], c = tp[2];
-                TriV tr = widen(a, b, c);
-                if (STATS) n_tris += 1;
-                double t, v, w;
-                if (!tri_test(tr, o, d, t_min, t_max, t, v, w)) continue;
-                uint32_t gid = (uint32_t)__float_as_int(a.w);
-                // the reference accepts t == t_max (triangle_mesh.rs:113) and keeps the candidate
-                // tested last; the build-defined rule keeps the lowest triangle id
-                if (best != PT_MISS && !(t < t_max || gid < best_id)) continue;
-                best = first + k; best_id = gid; t_max = t;
-                if (ANY) return best;
-            }
+    while (cur != kDone) {
+        while (cur >= 0) cur = node_step<DEPTH, STATS>(sc, cur, o, inv, t_min, t_max, stk, sp, n_nodes);
+        if (cur == kDone) break;
+        int code = ~cur;
+        uint32_t first = (uint32_t)code >> 3, cnt = ((uint32_t)code & 7u) + 1u;
+        for (uint32_t k = 0; k < cnt; ++k) {
+            const float4* tp = sc.tris + (size_t)(first + k) * 3;
+            float4 a = tp[0], b = tp[1], c = tp[2];
+            TriV tr = widen(a, b, c);
+            if (STATS) n_tris += 1;
+            double t, v, w;
+            if (!tri_test(tr, o, d, t_min, t_max, t, v, w)) continue;
+            uint32_t gid = (uint32_t)__float_as_int(a.w);
+            // the reference accepts t == t_max (triangle_mesh.rs:113) and keeps the candidate
+            // tested last; the build-defined rule keeps the lowest triangle id
+            if (best != PT_MISS && !(t < t_max || gid < best_id)) continue;
+            best = first + k; best_id = gid; t_max = t;
+            if (ANY) return best;
         }
         if (sp == 0) break;
         --sp;
