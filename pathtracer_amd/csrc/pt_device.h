@@ -103,6 +103,7 @@ struct Counters {  // device-side statistics (pt_stats)
 
 constexpr int kStackDepth = 32;  // LDS traversal stack entries per lane; builder bounds tree depth
 constexpr int kBlock = 256;
+constexpr int kTravBlock = 64;  // extend / shadow: one wave per workgroup, LDS and registers are released per wave
 
 // ---- launchers (pt_kernels.hip) ---------------------------------------------------------------
 void launch_generate_rays(const Scene& sc, const Frame& fr, double* rays_out /* pt_ray[n] */, hipStream_t st);

@@ -172,14 +172,14 @@ __device__ __forceinline__ int node_step(const Scene& sc, int cur, D3 o, D3 inv,
     if (h0 && h1) {
         int nearc = c0, farc = c1;
         if (tn1 < tn0) { nearc = c1; farc = c0; }
-        if (sp < DEPTH) { stk[sp * kBlock] = farc; ++sp; }
+        if (sp < DEPTH) { stk[sp * kTravBlock] = farc; ++sp; }
         return nearc;
     }
     if (h0) return c0;
     if (h1) return c1;
     if (sp == 0) return kDone;
     --sp;
-    return stk[sp * kBlock];
+    return stk[sp * kTravBlock];
 }
 
 // BVH traversal, one ray per lane, stack in LDS laid out [entry][lane] (bank = lane: conflict-free).
@@ -216,35 +216,41 @@ __device__ __forceinline__ uint32_t traverse(const Scene& sc, D3 o, D3 d, double
         }
         if (sp == 0) break;
         --sp;
-        cur = stk[sp * kBlock];
+        cur = stk[sp * kTravBlock];
     }
     return best;
 }
 
-// XCD-aware block remap: hardware deals consecutive workgroups round-robin over the 8 XCDs, so
-// blocks b and b+8 share an L2.  Give every XCD one contiguous eighth of the queue (for primary
-// rays: a contiguous band of the image) so each L2 caches its own part of the scene.
-__device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t nb) {
-    uint32_t q = nb >> 3, r = nb & 7u, x = b & 7u, k = b >> 3;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+// XCD-aware block remap.  Hardware deals consecutive workgroups round-robin over the 8 XCDs, so
+// blocks b and b+8 share an L2.  Work is handed out in chunks of kChunk consecutive blocks
+// (kChunk * 64 rays = a few image rows of primary rays): XCD x processes chunks x, x+8, x+16, ...
+// Consecutive rays stay on one L2 (locality for node/triangle fetches) while every XCD sees the
+// same mix of cheap and expensive regions (a contiguous eighth per XCD left XCDs idle: the ceiling
+// band finishes long before the heightfield band).  Bijective on [0, nb) when nb % (8*kChunk) == 0.
+constexpr uint32_t kChunk = 64;
+__device__ __forceinline__ uint32_t xcd_block(uint32_t b) {
+    uint32_t x = b & 7u, k = b >> 3;
+    return ((k / kChunk) * 8u + x) * kChunk + (k % kChunk);
+}
+__host__ __device__ __forceinline__ uint32_t trav_blocks(uint32_t n) {  // blocks for n rays, padded to whole chunk rounds
+    uint32_t nb = (n + kTravBlock - 1) / kTravBlock, r = 8u * kChunk;
+    return (nb + r - 1) / r * r;
 }
 
 // PRIMARY: the generate stage (main.rs:412-427 + scene.rs:37-45) runs in the prologue — lane i is
 // path slot i of the batch and builds its camera ray in registers; nothing is read from the queue.
 template <int DEPTH, bool STATS, bool PRIMARY>
-__global__ __launch_bounds__(kBlock) void k_extend(Scene sc, Frame fr, Queue q, const double* __restrict__ tmin,
+__global__ __launch_bounds__(kTravBlock) void k_extend(Scene sc, Frame fr, Queue q, const double* __restrict__ tmin,
                                                    const double* __restrict__ tmax,
                                                    const uint32_t* __restrict__ count, uint32_t n_max, Hits hits,
                                                    Counters* ctr) {
-    __shared__ int stack[DEPTH * kBlock];
+    __shared__ int stack[DEPTH * kTravBlock];
     uint32_t n = count ? min(*count, n_max) : n_max;
     if (ctr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->rays, (unsigned long long)n);
-    // the grid is sized for n_max; only the first ceil(n / kBlock) blocks have work, and those are
-    // the ones spread over the XCDs (remapping over gridDim would leave whole XCDs idle when n < n_max)
-    uint32_t nb_live = (n + kBlock - 1) / kBlock;
-    if (blockIdx.x >= nb_live) return;
-    uint32_t blk = xcd_block(blockIdx.x, nb_live);
-    uint32_t i = blk * kBlock + threadIdx.x;
+    // the grid is sized for n_max; only the first trav_blocks(n) blocks take part, so the live rays
+    // are spread over all XCDs whatever the live count is
+    if (blockIdx.x >= trav_blocks(n)) return;
+    uint32_t i = xcd_block(blockIdx.x) * kTravBlock + threadIdx.x;
     if (i >= n) return;
     D3 o, d;
     if (PRIMARY) {
@@ -277,14 +283,13 @@ __global__ __launch_bounds__(kBlock) void k_extend(Scene sc, Frame fr, Queue q, 
 }
 
 template <int DEPTH>
-__global__ __launch_bounds__(kBlock) void k_shadow(Scene sc, ShadowQueue sq, const uint32_t* __restrict__ count,
+__global__ __launch_bounds__(kTravBlock) void k_shadow(Scene sc, ShadowQueue sq, const uint32_t* __restrict__ count,
                                                    uint32_t n_max, Sample3 ls, Counters* ctr) {
-    __shared__ int stack[DEPTH * kBlock];
+    __shared__ int stack[DEPTH * kTravBlock];
     uint32_t n = min(*count, n_max);
     if (ctr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->shadow_rays, (unsigned long long)n);
-    uint32_t nb_live = (n + kBlock - 1) / kBlock;
-    if (blockIdx.x >= nb_live) return;
-    uint32_t i = xcd_block(blockIdx.x, nb_live) * kBlock + threadIdx.x;
+    if (blockIdx.x >= trav_blocks(n)) return;
+    uint32_t i = xcd_block(blockIdx.x) * kTravBlock + threadIdx.x;
     if (i >= n) return;
     D3 o = mk(sq.o[0][i], sq.o[1][i], sq.o[2][i]);
     D3 d = mk(sq.d[0][i], sq.d[1][i], sq.d[2][i]);
@@ -818,7 +823,7 @@ void launch_generate_rays(const Scene& sc, const Frame& fr, double* rays_out, hi
 template <bool STATS, bool PRIMARY>
 static void launch_extend_t(const Scene& sc, const Frame& fr, Queue q, const double* tmin, const double* tmax,
                             const uint32_t* count, uint32_t n_max, Hits hits, Counters* ctr, hipStream_t st) {
-    dim3 g(blocks_for(n_max)), b(kBlock);
+    dim3 g(trav_blocks(n_max)), b(kTravBlock);
     if (sc.bvh_depth <= 8) hipLaunchKernelGGL((k_extend<8, STATS, PRIMARY>), g, b, 0, st, sc, fr, q, tmin, tmax, count, n_max, hits, ctr);
     else if (sc.bvh_depth <= 16) hipLaunchKernelGGL((k_extend<16, STATS, PRIMARY>), g, b, 0, st, sc, fr, q, tmin, tmax, count, n_max, hits, ctr);
     else hipLaunchKernelGGL((k_extend<32, STATS, PRIMARY>), g, b, 0, st, sc, fr, q, tmin, tmax, count, n_max, hits, ctr);
@@ -859,7 +864,7 @@ void launch_shade(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, H
 void launch_shadow(const Scene& sc, ShadowQueue sq, const uint32_t* count, uint32_t n_max, Sample3 ls, Counters* ctr,
                    hipStream_t st) {
     if (!n_max) return;
-    dim3 g(blocks_for(n_max)), b(kBlock);
+    dim3 g(trav_blocks(n_max)), b(kTravBlock);
     if (sc.bvh_depth <= 8) hipLaunchKernelGGL(k_shadow<8>, g, b, 0, st, sc, sq, count, n_max, ls, ctr);
     else if (sc.bvh_depth <= 16) hipLaunchKernelGGL(k_shadow<16>, g, b, 0, st, sc, sq, count, n_max, ls, ctr);
     else hipLaunchKernelGGL(k_shadow<32>, g, b, 0, st, sc, sq, count, n_max, ls, ctr);
