@@ -75,8 +75,10 @@ struct Carver {  // carves 256-byte aligned arrays out of one allocation
     }
 };
 
-constexpr uint32_t kMaxBounces = 61;  // counters[] holds one queue counter per bounce
-constexpr uint32_t kCounterWords = 128;
+constexpr uint32_t kMaxBounces = 61;
+// counters[]: kSegs segment counters per bounce for the path queue, then the same for the shadow queue
+constexpr uint32_t kCounterSets = kMaxBounces + 3;
+constexpr uint32_t kCounterWords = 2 * kCounterSets * ptd::kSegs;
 
 struct Workspace {
     DevBuf buf;
@@ -86,13 +88,17 @@ struct Workspace {
     ptd::Hits hits;
     ptd::ShadowQueue sq;
     ptd::Sample3 ls;
-    uint32_t* counters = nullptr;  // [0..63] path queue counts per bounce, [64..127] shadow queue counts
+    uint32_t* counters = nullptr;
+    uint32_t seg_size = 0;
     DevBuf jitter;
     uint64_t jitter_cap = 0;
 };
 
-void carve_workspace(Workspace& w, void* base, uint32_t slots, bool nee, size_t& total) {
+void carve_workspace(Workspace& w, void* base, uint32_t n_slots, bool nee, size_t& total) {
     Carver c(base);
+    // queues, hit records and the shadow queue are segmented (ptd::kSegs segments); Lsample is per slot
+    const uint32_t slots = ptd::kSegs * ptd::seg_size_for(n_slots);
+    w.seg_size = ptd::seg_size_for(n_slots);
     for (int k = 0; k < 2; ++k) {
         for (int a = 0; a < 3; ++a) w.q[k].o[a] = c.take<double>(slots);
         for (int a = 0; a < 3; ++a) w.q[k].d[a] = c.take<double>(slots);
@@ -102,7 +108,7 @@ void carve_workspace(Workspace& w, void* base, uint32_t slots, bool nee, size_t&
     }
     w.hits.tri = c.take<uint32_t>(slots);
     w.hits.t = c.take<double>(slots);
-    for (int a = 0; a < 3; ++a) w.ls.c[a] = c.take<double>(slots);
+    for (int a = 0; a < 3; ++a) w.ls.c[a] = c.take<double>(n_slots);
     if (nee) {
         for (int a = 0; a < 3; ++a) w.sq.o[a] = c.take<double>(slots);
         for (int a = 0; a < 3; ++a) w.sq.d[a] = c.take<double>(slots);
@@ -535,23 +541,30 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
         HIP_TRY(hipMemsetAsync(w.counters, 0, kCounterWords * sizeof(uint32_t), st));
         // the generate stage is fused into the bounce-0 extend and shade kernels (they rebuild the
         // camera ray from the pixel): no primary-ray queue is written or read.
+        const uint32_t seg = ptd::seg_size_for(n_max);  // <= w.seg_size: the workspace was carved for >= n_max slots
+        const uint32_t cap = ptd::kSegs * seg;
+        uint32_t* path_cnt = w.counters;
+        uint32_t* shad_cnt = w.counters + kCounterSets * ptd::kSegs;
         for (uint32_t bounce = 0; bounce <= P->max_bounces; ++bounce) {
-            const uint32_t* cnt = bounce == 0 ? nullptr : w.counters + bounce;
+            // bounce 0 runs over the dense slot range; later bounces over the segmented queue
+            ptd::Live live = bounce == 0 ? ptd::Live{nullptr, 0, n_max}
+                                         : ptd::Live{path_cnt + bounce * ptd::kSegs, seg, cap};
+            ptd::Push push{path_cnt + (bounce + 1) * ptd::kSegs, seg};
+            ptd::Push spush{shad_cnt + bounce * ptd::kSegs, seg};
             ptd::Queue& qin = w.q[bounce & 1];
             ptd::Queue& qout = w.q[(bounce + 1) & 1];
             {
                 Timer t(s, st, PT_K_EXTEND);
                 if (bounce == 0) ptd::launch_extend_primary(s->dev, fr, w.hits, ctr, stats, st);
-                else ptd::launch_extend(s->dev, qin, nullptr, nullptr, cnt, n_max, w.hits, ctr, stats, st);
+                else ptd::launch_extend(s->dev, qin, nullptr, nullptr, live, w.hits, ctr, stats, st);
             }
             {
                 Timer t(s, st, PT_K_SHADE);
-                ptd::launch_shade(s->dev, fr, bounce, qin, w.hits, cnt, n_max, qout, w.counters + bounce + 1, w.sq,
-                                  w.counters + 64 + bounce, w.ls, st);
+                ptd::launch_shade(s->dev, fr, bounce, qin, w.hits, live, qout, push, w.sq, spush, w.ls, st);
             }
             if (nee && bounce < P->max_bounces) {
                 Timer t(s, st, PT_K_SHADOW);
-                ptd::launch_shadow(s->dev, w.sq, w.counters + 64 + bounce, n_max, w.ls, ctr, st);
+                ptd::launch_shadow(s->dev, w.sq, ptd::Live{spush.counts, seg, cap}, w.ls, ctr, st);
             }
         }
         {
@@ -612,7 +625,7 @@ int pt_trace_closest(pt_scene* s, const pt_ray* rays, size_t n, uint32_t* tri_id
         hits.tri = (uint32_t*)(db + (size_t)9 * m);
         {
             Timer tm(s, nullptr, PT_K_EXTEND);
-            ptd::launch_extend(s->dev, q, db + (size_t)6 * m, db + (size_t)7 * m, nullptr, m, hits,
+            ptd::launch_extend(s->dev, q, db + (size_t)6 * m, db + (size_t)7 * m, ptd::Live{nullptr, 0, m}, hits,
                                s->d_ctr.as<ptd::Counters>(), s->profiling >= 2, nullptr);
         }
         ptd::launch_leaf_to_global(s->dev, hits.tri, m, nullptr);

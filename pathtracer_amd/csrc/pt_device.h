@@ -85,6 +85,26 @@ struct ShadowQueue {
     uint32_t* slot;
 };
 
+// Queues are appended to by many workgroups at once.  One shared counter would serialise every
+// append on a single L2 atomic (measured: ~90-140 appends/us, which bounded the shade kernel), so a
+// queue is cut into kSegs segments of `seg_size` entries, each with its own counter; workgroup b
+// appends to segment b % kSegs.  All segments fill evenly, entries stay dense inside a segment,
+// and a consumer workgroup (seg_size is a multiple of the block size) lies inside one segment.
+constexpr uint32_t kSegs = 64;
+struct Live {                 // which entries of a queue are live
+    const uint32_t* counts;   // nullptr: dense, entries [0, n) are live
+    uint32_t seg_size;        // segmented: entry i is live iff i % seg_size < counts[i / seg_size]
+    uint32_t n;               // dense: live count; segmented: kSegs * seg_size (index range)
+};
+struct Push {                 // where survivors are appended
+    uint32_t* counts;         // kSegs counters, zeroed by the host before the launch
+    uint32_t seg_size;
+};
+inline uint32_t seg_size_for(uint32_t n_max) {  // entries per segment so that kSegs segments hold any output of n_max lanes
+    uint32_t blocks = (n_max + 255u) / 256u;
+    return ((blocks + kSegs - 1) / kSegs) * 256u;
+}
+
 struct Frame {  // per-call constants of generate / shade
     uint32_t width, height;
     uint32_t x0, y0, tile_w, tile_h;
@@ -108,14 +128,12 @@ constexpr int kTravBlock = 64;  // extend / shadow: one wave per workgroup, LDS 
 // ---- launchers (pt_kernels.hip) ---------------------------------------------------------------
 void launch_generate_rays(const Scene& sc, const Frame& fr, double* rays_out /* pt_ray[n] */, hipStream_t st);
 // count == nullptr -> n_max rays are live
-void launch_extend(const Scene& sc, Queue q, const double* tmin, const double* tmax, const uint32_t* count,
-                   uint32_t n_max, Hits hits, Counters* ctr, bool stats, hipStream_t st);
+void launch_extend(const Scene& sc, Queue q, const double* tmin, const double* tmax, Live live, Hits hits,
+                   Counters* ctr, bool stats, hipStream_t st);
 void launch_extend_primary(const Scene& sc, const Frame& fr, Hits hits, Counters* ctr, bool stats, hipStream_t st);
-void launch_shade(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, Hits hits, const uint32_t* count,
-                  uint32_t n_max, Queue out, uint32_t* out_count, ShadowQueue sq, uint32_t* sq_count,
-                  Sample3 lsample, hipStream_t st);
-void launch_shadow(const Scene& sc, ShadowQueue sq, const uint32_t* count, uint32_t n_max, Sample3 lsample,
-                   Counters* ctr, hipStream_t st);
+void launch_shade(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, Hits hits, Live live, Queue out,
+                  Push out_push, ShadowQueue sq, Push sq_push, Sample3 lsample, hipStream_t st);
+void launch_shadow(const Scene& sc, ShadowQueue sq, Live live, Sample3 lsample, Counters* ctr, hipStream_t st);
 void launch_accumulate(const Frame& fr, Sample3 lsample, double* accum, hipStream_t st);
 // parity entry points
 void launch_leaf_to_global(const Scene& sc, uint32_t* tri, uint32_t n, hipStream_t st);

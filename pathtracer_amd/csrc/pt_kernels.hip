@@ -221,6 +221,20 @@ __device__ __forceinline__ uint32_t traverse(const Scene& sc, D3 o, D3 d, double
     return best;
 }
 
+// Exclusive end of the live entries in the segment that holds entry i0 (i0 = first entry of a
+// workgroup; a workgroup never straddles segments).  Dense queues have one segment [0, n).
+__device__ __forceinline__ uint32_t live_end(const Live& lv, uint32_t i0) {
+    if (!lv.counts) return lv.n;
+    uint32_t seg = i0 / lv.seg_size;
+    return seg * lv.seg_size + min(lv.counts[seg], lv.seg_size);
+}
+__device__ __forceinline__ unsigned long long live_total(const Live& lv) {
+    if (!lv.counts) return lv.n;
+    unsigned long long t = 0;
+    for (uint32_t k = 0; k < kSegs; ++k) t += min(lv.counts[k], lv.seg_size);
+    return t;
+}
+
 // XCD-aware block remap.  Hardware deals consecutive workgroups round-robin over the 8 XCDs, so
 // blocks b and b+8 share an L2.  Work is handed out in chunks of kChunk consecutive blocks
 // (kChunk * 64 rays = a few image rows of primary rays): XCD x processes chunks x, x+8, x+16, ...
@@ -241,17 +255,22 @@ __host__ __device__ __forceinline__ uint32_t trav_blocks(uint32_t n) {  // block
 // path slot i of the batch and builds its camera ray in registers; nothing is read from the queue.
 template <int DEPTH, bool STATS, bool PRIMARY>
 __global__ __launch_bounds__(kTravBlock) void k_extend(Scene sc, Frame fr, Queue q, const double* __restrict__ tmin,
-                                                   const double* __restrict__ tmax,
-                                                   const uint32_t* __restrict__ count, uint32_t n_max, Hits hits,
+                                                   const double* __restrict__ tmax, Live live, Hits hits,
                                                    Counters* ctr) {
     __shared__ int stack[DEPTH * kTravBlock];
-    uint32_t n = count ? min(*count, n_max) : n_max;
-    if (ctr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->rays, (unsigned long long)n);
-    // the grid is sized for n_max; only the first trav_blocks(n) blocks take part, so the live rays
-    // are spread over all XCDs whatever the live count is
-    if (blockIdx.x >= trav_blocks(n)) return;
-    uint32_t i = xcd_block(blockIdx.x) * kTravBlock + threadIdx.x;
-    if (i >= n) return;
+    if (ctr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->rays, live_total(live));
+    uint32_t i;
+    if (live.counts) {
+        // segmented queue: live entries are already spread evenly over the index range, and the
+        // hardware's round-robin block placement spreads them over the XCDs
+        i = blockIdx.x * kTravBlock + threadIdx.x;
+        if (i >= live.n || i >= live_end(live, blockIdx.x * kTravBlock)) return;
+    } else {
+        // dense queue [0, n): only the first trav_blocks(n) blocks take part, remapped in chunks
+        if (blockIdx.x >= trav_blocks(live.n)) return;
+        i = xcd_block(blockIdx.x) * kTravBlock + threadIdx.x;
+        if (i >= live.n) return;
+    }
     D3 o, d;
     if (PRIMARY) {
         uint32_t s = i / fr.n_tile_pixels, p = i - s * fr.n_tile_pixels;
@@ -283,14 +302,11 @@ __global__ __launch_bounds__(kTravBlock) void k_extend(Scene sc, Frame fr, Queue
 }
 
 template <int DEPTH>
-__global__ __launch_bounds__(kTravBlock) void k_shadow(Scene sc, ShadowQueue sq, const uint32_t* __restrict__ count,
-                                                   uint32_t n_max, Sample3 ls, Counters* ctr) {
+__global__ __launch_bounds__(kTravBlock) void k_shadow(Scene sc, ShadowQueue sq, Live live, Sample3 ls, Counters* ctr) {
     __shared__ int stack[DEPTH * kTravBlock];
-    uint32_t n = min(*count, n_max);
-    if (ctr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->shadow_rays, (unsigned long long)n);
-    if (blockIdx.x >= trav_blocks(n)) return;
-    uint32_t i = xcd_block(blockIdx.x) * kTravBlock + threadIdx.x;
-    if (i >= n) return;
+    if (ctr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->shadow_rays, live_total(live));
+    uint32_t i = blockIdx.x * kTravBlock + threadIdx.x;
+    if (i >= live.n || i >= live_end(live, blockIdx.x * kTravBlock)) return;
     D3 o = mk(sq.o[0][i], sq.o[1][i], sq.o[2][i]);
     D3 d = mk(sq.d[0][i], sq.d[1][i], sq.d[2][i]);
     double t_max = sq.tmax[i];
@@ -583,15 +599,16 @@ __device__ __forceinline__ uint32_t compact_slot(bool alive, uint32_t* counter, 
 //           even loaded unless NEE needs them for the MIS weight.
 template <bool FIRST, bool LAST, bool NEE>
 __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t bounce, Queue in, Hits hits,
-                                                  const uint32_t* __restrict__ count, uint32_t n_max, Queue out,
-                                                  uint32_t* out_count, ShadowQueue sq, uint32_t* sq_count,
+                                                  Live live, Queue out, Push out_push, ShadowQueue sq, Push sq_push,
                                                   Sample3 ls) {
     __shared__ uint32_t lds_a[kBlock / 64 + 1];
     __shared__ uint32_t lds_b[kBlock / 64 + 1];
-    uint32_t n = count ? min(*count, n_max) : n_max;
+    if (blockIdx.x * kBlock >= live.n) return;
+    uint32_t n = live_end(live, blockIdx.x * kBlock);
     if (blockIdx.x * kBlock >= n) return;  // whole block idle
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     bool active = i < n;
+    const uint32_t region = blockIdx.x % kSegs;  // the segment this workgroup appends to
     bool alive = false, shadow = false;
     uint32_t slot = 0;
     D3 n_o = mk(0, 0, 0), n_d = n_o, n_T = n_o;
@@ -706,7 +723,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
         }
     }
     if (LAST) return;  // nothing continues
-    uint32_t pos = compact_slot(alive, out_count, lds_a);
+    uint32_t pos = region * out_push.seg_size + compact_slot(alive, out_push.counts + region, lds_a);
     if (alive) {
         out.o[0][pos] = n_o.x; out.o[1][pos] = n_o.y; out.o[2][pos] = n_o.z;
         out.d[0][pos] = n_d.x; out.d[1][pos] = n_d.y; out.d[2][pos] = n_d.z;
@@ -715,7 +732,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
         if (NEE) out.prev_pdf[pos] = n_pdf;
     }
     if (NEE) {
-        uint32_t spos = compact_slot(shadow, sq_count, lds_b);
+        uint32_t spos = region * sq_push.seg_size + compact_slot(shadow, sq_push.counts + region, lds_b);
         if (shadow) {
             sq.o[0][spos] = n_o.x; sq.o[1][spos] = n_o.y; sq.o[2][spos] = n_o.z;
             sq.d[0][spos] = s_d.x; sq.d[1][spos] = s_d.y; sq.d[2][spos] = s_d.z;
@@ -821,53 +838,52 @@ void launch_generate_rays(const Scene& sc, const Frame& fr, double* rays_out, hi
 // The LDS stack is sized for the scene's BVH depth: 8 / 16 / 32 entries per lane (8 / 16 / 32 KB per
 // block), so shallow trees do not pay occupancy for stack they cannot use.
 template <bool STATS, bool PRIMARY>
-static void launch_extend_t(const Scene& sc, const Frame& fr, Queue q, const double* tmin, const double* tmax,
-                            const uint32_t* count, uint32_t n_max, Hits hits, Counters* ctr, hipStream_t st) {
-    dim3 g(trav_blocks(n_max)), b(kTravBlock);
-    if (sc.bvh_depth <= 8) hipLaunchKernelGGL((k_extend<8, STATS, PRIMARY>), g, b, 0, st, sc, fr, q, tmin, tmax, count, n_max, hits, ctr);
-    else if (sc.bvh_depth <= 16) hipLaunchKernelGGL((k_extend<16, STATS, PRIMARY>), g, b, 0, st, sc, fr, q, tmin, tmax, count, n_max, hits, ctr);
-    else hipLaunchKernelGGL((k_extend<32, STATS, PRIMARY>), g, b, 0, st, sc, fr, q, tmin, tmax, count, n_max, hits, ctr);
+static void launch_extend_t(const Scene& sc, const Frame& fr, Queue q, const double* tmin, const double* tmax, Live live,
+                            Hits hits, Counters* ctr, hipStream_t st) {
+    dim3 g(live.counts ? (live.n + kTravBlock - 1) / kTravBlock : trav_blocks(live.n)), b(kTravBlock);
+    if (sc.bvh_depth <= 8) hipLaunchKernelGGL((k_extend<8, STATS, PRIMARY>), g, b, 0, st, sc, fr, q, tmin, tmax, live, hits, ctr);
+    else if (sc.bvh_depth <= 16) hipLaunchKernelGGL((k_extend<16, STATS, PRIMARY>), g, b, 0, st, sc, fr, q, tmin, tmax, live, hits, ctr);
+    else hipLaunchKernelGGL((k_extend<32, STATS, PRIMARY>), g, b, 0, st, sc, fr, q, tmin, tmax, live, hits, ctr);
 }
-void launch_extend(const Scene& sc, Queue q, const double* tmin, const double* tmax, const uint32_t* count,
-                   uint32_t n_max, Hits hits, Counters* ctr, bool stats, hipStream_t st) {
-    if (!n_max) return;
+void launch_extend(const Scene& sc, Queue q, const double* tmin, const double* tmax, Live live, Hits hits,
+                   Counters* ctr, bool stats, hipStream_t st) {
+    if (!live.n) return;
     Frame fr{};
-    if (stats) launch_extend_t<true, false>(sc, fr, q, tmin, tmax, count, n_max, hits, ctr, st);
-    else launch_extend_t<false, false>(sc, fr, q, tmin, tmax, count, n_max, hits, ctr, st);
+    if (stats) launch_extend_t<true, false>(sc, fr, q, tmin, tmax, live, hits, ctr, st);
+    else launch_extend_t<false, false>(sc, fr, q, tmin, tmax, live, hits, ctr, st);
 }
 void launch_extend_primary(const Scene& sc, const Frame& fr, Hits hits, Counters* ctr, bool stats, hipStream_t st) {
     uint32_t n = fr.n_tile_pixels * fr.n_samples;
     if (!n) return;
     Queue q{};
-    if (stats) launch_extend_t<true, true>(sc, fr, q, nullptr, nullptr, nullptr, n, hits, ctr, st);
-    else launch_extend_t<false, true>(sc, fr, q, nullptr, nullptr, nullptr, n, hits, ctr, st);
+    Live live{nullptr, 0, n};
+    if (stats) launch_extend_t<true, true>(sc, fr, q, nullptr, nullptr, live, hits, ctr, st);
+    else launch_extend_t<false, true>(sc, fr, q, nullptr, nullptr, live, hits, ctr, st);
 }
 template <bool FIRST, bool LAST>
 static void launch_shade_t(bool nee, dim3 g, dim3 b, hipStream_t st, const Scene& sc, const Frame& fr, uint32_t bounce,
-                           Queue in, Hits hits, const uint32_t* count, uint32_t n_max, Queue out, uint32_t* out_count,
-                           ShadowQueue sq, uint32_t* sq_count, Sample3 ls) {
-    if (nee) hipLaunchKernelGGL((k_shade<FIRST, LAST, true>), g, b, 0, st, sc, fr, bounce, in, hits, count, n_max, out, out_count, sq, sq_count, ls);
-    else hipLaunchKernelGGL((k_shade<FIRST, LAST, false>), g, b, 0, st, sc, fr, bounce, in, hits, count, n_max, out, out_count, sq, sq_count, ls);
+                           Queue in, Hits hits, Live live, Queue out, Push out_push, ShadowQueue sq, Push sq_push,
+                           Sample3 ls) {
+    if (nee) hipLaunchKernelGGL((k_shade<FIRST, LAST, true>), g, b, 0, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls);
+    else hipLaunchKernelGGL((k_shade<FIRST, LAST, false>), g, b, 0, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls);
 }
-void launch_shade(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, Hits hits, const uint32_t* count,
-                  uint32_t n_max, Queue out, uint32_t* out_count, ShadowQueue sq, uint32_t* sq_count, Sample3 ls,
-                  hipStream_t st) {
-    if (!n_max) return;
+void launch_shade(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, Hits hits, Live live, Queue out,
+                  Push out_push, ShadowQueue sq, Push sq_push, Sample3 ls, hipStream_t st) {
+    if (!live.n) return;
     bool nee = (fr.flags & PT_FLAG_NEE) != 0 && sc.n_lights > 0;
     bool first = bounce == 0, last = bounce >= fr.max_bounces;
-    dim3 g(blocks_for(n_max)), b(kBlock);
-    if (first && last) launch_shade_t<true, true>(nee, g, b, st, sc, fr, bounce, in, hits, count, n_max, out, out_count, sq, sq_count, ls);
-    else if (first) launch_shade_t<true, false>(nee, g, b, st, sc, fr, bounce, in, hits, count, n_max, out, out_count, sq, sq_count, ls);
-    else if (last) launch_shade_t<false, true>(nee, g, b, st, sc, fr, bounce, in, hits, count, n_max, out, out_count, sq, sq_count, ls);
-    else launch_shade_t<false, false>(nee, g, b, st, sc, fr, bounce, in, hits, count, n_max, out, out_count, sq, sq_count, ls);
+    dim3 g(blocks_for(live.n)), b(kBlock);
+    if (first && last) launch_shade_t<true, true>(nee, g, b, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls);
+    else if (first) launch_shade_t<true, false>(nee, g, b, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls);
+    else if (last) launch_shade_t<false, true>(nee, g, b, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls);
+    else launch_shade_t<false, false>(nee, g, b, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls);
 }
-void launch_shadow(const Scene& sc, ShadowQueue sq, const uint32_t* count, uint32_t n_max, Sample3 ls, Counters* ctr,
-                   hipStream_t st) {
-    if (!n_max) return;
-    dim3 g(trav_blocks(n_max)), b(kTravBlock);
-    if (sc.bvh_depth <= 8) hipLaunchKernelGGL(k_shadow<8>, g, b, 0, st, sc, sq, count, n_max, ls, ctr);
-    else if (sc.bvh_depth <= 16) hipLaunchKernelGGL(k_shadow<16>, g, b, 0, st, sc, sq, count, n_max, ls, ctr);
-    else hipLaunchKernelGGL(k_shadow<32>, g, b, 0, st, sc, sq, count, n_max, ls, ctr);
+void launch_shadow(const Scene& sc, ShadowQueue sq, Live live, Sample3 ls, Counters* ctr, hipStream_t st) {
+    if (!live.n) return;
+    dim3 g((live.n + kTravBlock - 1) / kTravBlock), b(kTravBlock);
+    if (sc.bvh_depth <= 8) hipLaunchKernelGGL(k_shadow<8>, g, b, 0, st, sc, sq, live, ls, ctr);
+    else if (sc.bvh_depth <= 16) hipLaunchKernelGGL(k_shadow<16>, g, b, 0, st, sc, sq, live, ls, ctr);
+    else hipLaunchKernelGGL(k_shadow<32>, g, b, 0, st, sc, sq, live, ls, ctr);
 }
 void launch_accumulate(const Frame& fr, Sample3 ls, double* accum, hipStream_t st) {
     if (!fr.n_tile_pixels) return;
