@@ -427,6 +427,9 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
     dv.n_tris = d->n_tris;
     dv.n_lights = (uint32_t)lights.size();
     dv.bvh_depth = s->depth;
+    dv.plain = 1;
+    for (uint32_t i = 0; i < d->n_mats; ++i)
+        if (d->mats[i].kind != PT_MAT_LAMBERT || d->mats[i].tex >= 0) dv.plain = 0;
     dv.light_area = acc;
     // scene.rs:38-42, hoisted out of Camera::ray
     H3 view{d->camera.view[0], d->camera.view[1], d->camera.view[2]};

@@ -55,6 +55,8 @@ struct Scene {
     const Light* lights;
     uint32_t n_nodes, n_tris, n_lights, bvh_depth;
     double light_area;
+    uint32_t plain;  // only untextured Lambertian materials (selects the lean shade kernel)
+    uint32_t pad;
     Camera cam;
     double background[3];
 };

@@ -597,7 +597,9 @@ __device__ __forceinline__ uint32_t compact_slot(bool alive, uint32_t* counter, 
 //   LAST  = bounce == max_bounces: only main.rs:299/307 remain (the reference still samples the
 //           BRDF there, main.rs:310, but nothing consumes it), so the ray and hit distance are not
 //           even loaded unless NEE needs them for the MIS weight.
-template <bool FIRST, bool LAST, bool NEE>
+//   PLAIN = the scene has only untextured Lambertian materials: the Glossy and texture code is
+//           compiled out, which is what keeps this kernel's register count (and occupancy) sane.
+template <bool FIRST, bool LAST, bool NEE, bool PLAIN>
 __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t bounce, Queue in, Hits hits,
                                                   Live live, Queue out, Push out_push, ShadowQueue sq, Push sq_push,
                                                   Sample3 ls) {
@@ -639,7 +641,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
         } else if (!kNeedRay) {
             uint32_t mat = (uint32_t)__float_as_int(sc.tris[(size_t)leaf * 3 + 1].w);
             const Material& m = sc.mats[mat];
-            D3 le = m.kind == PT_MAT_GLOSSY ? mk(0., 0., 0.) : ld3(m.emission);  // microfacet.rs:33-35
+            D3 le = (!PLAIN && m.kind == PT_MAT_GLOSSY) ? mk(0., 0., 0.) : ld3(m.emission);  // microfacet.rs:33-35
             add = T * le;  // main.rs:307
         } else {
             double t = hits.t[i];
@@ -648,7 +650,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
             D3 position, normal;
             hit_geometry(sc, leaf, o, d, t, tr, mat, position, normal);
             const Material& m = sc.mats[mat];
-            D3 le = m.kind == PT_MAT_GLOSSY ? mk(0., 0., 0.) : ld3(m.emission);  // microfacet.rs:33-35
+            D3 le = (!PLAIN && m.kind == PT_MAT_GLOSSY) ? mk(0., 0., 0.) : ld3(m.emission);  // microfacet.rs:33-35
             add = T * le;  // main.rs:307
             if (NEE && !FIRST && (le.x != 0. || le.y != 0. || le.z != 0.)) {
                 // MIS weight of a BRDF-sampled hit on a light (balance heuristic)
@@ -661,7 +663,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
             }
             if (!LAST) {
                 D3 diffuse = mk(0., 0., 0.);
-                if (m.kind != PT_MAT_GLOSSY) diffuse = diffuse_of(sc, m, tr, leaf, o, d, position, normal, fr, FIRST, pixel, s);
+                if (PLAIN) diffuse = ld3(m.color);
+                else if (m.kind != PT_MAT_GLOSSY) diffuse = diffuse_of(sc, m, tr, leaf, o, d, position, normal, fr, FIRST, pixel, s);
                 if (NEE && sc.n_lights) {
                     double r0, r1;
                     uniform2(fr.seed, pixel, sample, bounce, STREAM_LIGHT, r0, r1);
@@ -684,7 +687,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
                     D3 wl = diff / dist;
                     D3 wo = -d;
                     double p_b;
-                    if (m.kind == PT_MAT_GLOSSY) {
+                    if ((!PLAIN && m.kind == PT_MAT_GLOSSY)) {
                         double pg = glossy_pdf_dir(m.width, wo, wl, normal);
                         p_b = pg > 0. ? pg : 0.;
                     } else {
@@ -694,7 +697,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
                     double cos_l = fabs(dot(ld3(L.normal), wl));
                     double p_l = cos_l <= 0. ? 0. : dist * dist / (sc.light_area * cos_l);
                     if (p_l > 0. && p_b > 0. && dist > 0.) {
-                        D3 f = m.kind == PT_MAT_GLOSSY ? glossy_f(m.width, ld3(m.color), wo, wl, normal)
+                        D3 f = (!PLAIN && m.kind == PT_MAT_GLOSSY) ? glossy_f(m.width, ld3(m.color), wo, wl, normal)
                                                        : diffuse * PT_FRAC_1_PI;
                         double cosn = fabs(dot(wl, normal));
                         double wgt = p_l / (p_l + p_b);
@@ -706,7 +709,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
                 }
                 double xi1, xi2;
                 uniform2(fr.seed, pixel, sample, bounce, STREAM_BRDF, xi1, xi2);
-                Brdf bs = m.kind == PT_MAT_GLOSSY ? glossy_sample(m.width, ld3(m.color), d, normal, xi1, xi2)
+                Brdf bs = (!PLAIN && m.kind == PT_MAT_GLOSSY) ? glossy_sample(m.width, ld3(m.color), d, normal, xi1, xi2)
                                                   : lambertian_sample(diffuse, normal, xi1, xi2);
                 n_T = T * (bs.f * fabs(dot(bs.wi, normal)) / bs.pdf);  // main.rs:311
                 n_o = position;                                        // main.rs:314
@@ -864,8 +867,13 @@ template <bool FIRST, bool LAST>
 static void launch_shade_t(bool nee, dim3 g, dim3 b, hipStream_t st, const Scene& sc, const Frame& fr, uint32_t bounce,
                            Queue in, Hits hits, Live live, Queue out, Push out_push, ShadowQueue sq, Push sq_push,
                            Sample3 ls) {
-    if (nee) hipLaunchKernelGGL((k_shade<FIRST, LAST, true>), g, b, 0, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls);
-    else hipLaunchKernelGGL((k_shade<FIRST, LAST, false>), g, b, 0, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls);
+    if (sc.plain) {
+        if (nee) hipLaunchKernelGGL((k_shade<FIRST, LAST, true, true>), g, b, 0, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls);
+        else hipLaunchKernelGGL((k_shade<FIRST, LAST, false, true>), g, b, 0, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls);
+    } else {
+        if (nee) hipLaunchKernelGGL((k_shade<FIRST, LAST, true, false>), g, b, 0, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls);
+        else hipLaunchKernelGGL((k_shade<FIRST, LAST, false, false>), g, b, 0, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls);
+    }
 }
 void launch_shade(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, Hits hits, Live live, Queue out,
                   Push out_push, ShadowQueue sq, Push sq_push, Sample3 ls, hipStream_t st) {
