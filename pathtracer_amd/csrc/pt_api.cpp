@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -163,6 +164,28 @@ H3 hnorm(H3 a) {
     return {a.x / l, a.y / l, a.z / l};
 }
 H3 hneg(H3 a) { return {-a.x, -a.y, -a.z}; }
+
+// Traversal scheduling of a scene (pt_kernels.hip trace_range_vote / traverse).  Defaults from the
+// sweeps recorded in DESIGN.md "Traversal scheduling": primary rays one ray per lane; secondary and
+// shadow rays vote-scheduled over ranges of 256 rays when the tree is deeper than 8 levels (scenes
+// from ~500 triangles up).  Tuning runs and tests override it through the environment, read when
+// the scene is created: PT_TRAV_VOTE_PRIMARY / PT_TRAV_VOTE / PT_TRAV_VOTE_SHADOW = 0|1,
+// PT_WAVE_RAYS = 64..1024 (power of two).
+void resolve_scheduling(ptd::Scene& dv) {
+    auto flag = [](const char* name, bool dflt) {
+        const char* e = getenv(name);
+        return (uint8_t)((e && *e) ? atoi(e) != 0 : dflt);
+    };
+    const bool deep = dv.bvh_depth > 8;
+    dv.vote_primary = flag("PT_TRAV_VOTE_PRIMARY", false);
+    dv.vote_secondary = flag("PT_TRAV_VOTE", deep);
+    dv.vote_shadow = flag("PT_TRAV_VOTE_SHADOW", deep);
+    dv.wave_rays = 256;
+    if (const char* e = getenv("PT_WAVE_RAYS")) {
+        uint32_t r = (uint32_t)atoi(e);
+        if (r >= 64 && r <= ptd::kSegAlign && (r & (r - 1)) == 0) dv.wave_rays = r;
+    }
+}
 
 template <class T>
 int upload(DevBuf& b, const T* src, size_t n) {
@@ -427,6 +450,7 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
     dv.n_tris = d->n_tris;
     dv.n_lights = (uint32_t)lights.size();
     dv.bvh_depth = s->depth;
+    resolve_scheduling(dv);
     dv.plain = 1;
     for (uint32_t i = 0; i < d->n_mats; ++i)
         if (d->mats[i].kind != PT_MAT_LAMBERT || d->mats[i].tex >= 0) dv.plain = 0;

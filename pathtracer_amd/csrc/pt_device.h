@@ -56,6 +56,10 @@ struct Scene {
     uint32_t n_nodes, n_tris, n_lights, bvh_depth;
     double light_area;
     uint32_t plain;  // only untextured Lambertian materials (selects the lean shade kernel)
+    // traversal scheduling, resolved at scene creation (pt_api.cpp resolve_scheduling): vote-
+    // scheduled ranges of wave_rays rays per wave, or one ray per lane
+    uint8_t vote_primary, vote_secondary, vote_shadow;
+    uint32_t wave_rays;
     uint32_t pad;
     Camera cam;
     double background[3];
@@ -93,6 +97,10 @@ struct ShadowQueue {
 // appends to segment b % kSegs.  All segments fill evenly, entries stay dense inside a segment,
 // and a consumer workgroup (seg_size is a multiple of the block size) lies inside one segment.
 constexpr uint32_t kSegs = 64;
+// extend / shadow: one wave works through a range of 64..kSegAlign consecutive entries (64 at a
+// time, a finished lane takes the next one).  Segment sizes are multiples of kSegAlign, so such a
+// range lies inside one segment.
+constexpr uint32_t kSegAlign = 1024;
 struct Live {                 // which entries of a queue are live
     const uint32_t* counts;   // nullptr: dense, entries [0, n) are live
     uint32_t seg_size;        // segmented: entry i is live iff i % seg_size < counts[i / seg_size]
@@ -104,7 +112,8 @@ struct Push {                 // where survivors are appended
 };
 inline uint32_t seg_size_for(uint32_t n_max) {  // entries per segment so that kSegs segments hold any output of n_max lanes
     uint32_t blocks = (n_max + 255u) / 256u;
-    return ((blocks + kSegs - 1) / kSegs) * 256u;
+    uint32_t seg = ((blocks + kSegs - 1) / kSegs) * 256u;
+    return (seg + kSegAlign - 1) / kSegAlign * kSegAlign;
 }
 
 struct Frame {  // per-call constants of generate / shade

@@ -182,11 +182,86 @@ __device__ __forceinline__ int node_step(const Scene& sc, int cur, D3 o, D3 inv,
     return stk[sp * kTravBlock];
 }
 
-// BVH traversal, one ray per lane, stack in LDS laid out [entry][lane] (bank = lane: conflict-free).
-// ANY = stop at the first accepted triangle (shadow rays).  Returns leaf-order index / PT_MISS.
-// "while-while" form: the wave keeps stepping through inner nodes until every lane holds a leaf
-// (or is done), then all of them run the expensive triangle tests together; lanes of a wave
-// diverge less than with one node-or-leaf step per iteration.
+// BVH traversal of the rays [begin, end) by one wave, stack in LDS laid out [entry][lane]
+// (bank = lane: conflict-free).  ANY = stop at the first accepted triangle (shadow rays).
+//
+// Every lane is a small state machine whose next unit of work is one of
+//   node   (cur >= 0)             slab-test the two children of an inner node, descend / push / pop
+//   tri    (cur < 0, != kDone)    test ONE triangle of the leaf range encoded in cur, advance / pop
+//   retire (cur == kDone)         hand the finished ray to done() and claim the next unclaimed ray
+//                                 of the wave's range (ballot + mbcnt rank: no atomics, no memory)
+// and each trip of the loop the wave runs only the kind most of its lanes are waiting for (a
+// ballot vote).  The chosen body therefore runs with at least a third — typically well over half —
+// of the working lanes active, whatever mix of cheap and expensive rays the wave holds.  The
+// one-ray-per-lane while-while form measured 16 % lane utilisation on incoherent secondary rays
+// of the 10M-triangle scene: every lane waited for the longest descent, the largest leaf and the
+// longest ray of its 64.
+// fetch(idx, o, d, t_min, t_max) loads ray idx; done(idx, leaf_tri, t) consumes its result.
+template <int DEPTH, bool ANY, bool STATS, class Fetch, class Done>
+__device__ __forceinline__ void trace_range_vote(const Scene& sc, uint32_t begin, uint32_t end, int* stk, Fetch fetch,
+                                                 Done done, uint32_t& n_nodes, uint32_t& n_tris) {
+    uint32_t cursor = begin;  // wave-uniform: first unclaimed ray
+    bool busy = false;
+    uint32_t idx = 0, best = PT_MISS, best_id = PT_MISS;
+    D3 o = mk(0., 0., 0.), d = o, inv = o;
+    double t_min = 0., t_max = 0.;
+    int sp = 0, cur = kDone;
+    for (;;) {
+        const bool is_node = cur >= 0, is_ret = cur == kDone && (busy || cursor < end);
+        const bool is_tri = cur < 0 && cur != kDone;
+        const unsigned long long m_ret = __ballot(is_ret);
+        const int n_node = __popcll(__ballot(is_node)), n_tri = __popcll(__ballot(is_tri)), n_ret = __popcll(m_ret);
+        if (n_node >= n_tri && n_node >= n_ret) {
+            if (n_node == 0) break;  // nothing left in the range
+            if (is_node) cur = node_step<DEPTH, STATS>(sc, cur, o, inv, t_min, t_max, stk, sp, n_nodes);
+        } else if (n_tri >= n_ret) {
+            if (is_tri) {
+                uint32_t code = (uint32_t)~cur, first = code >> 3, cnt = (code & 7u) + 1u;
+                bool stop = false;
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const float4* tp = sc.tris + (size_t)(first + k) * 3;
+                    float4 a = tp[0], b = tp[1], c = tp[2];
+                    TriV tr = widen(a, b, c);
+                    if (STATS) n_tris += 1;
+                    double t, v, w;
+                    if (!tri_test(tr, o, d, t_min, t_max, t, v, w)) continue;
+                    uint32_t gid = (uint32_t)__float_as_int(a.w);
+                    // the reference accepts t == t_max (triangle_mesh.rs:113) and keeps the candidate
+                    // tested last; the build-defined rule keeps the lowest triangle id
+                    if (best != PT_MISS && !(t < t_max || gid < best_id)) continue;
+                    best = first + k; best_id = gid; t_max = t;
+                    if (ANY) { stop = true; break; }
+                }
+                if (stop || sp == 0) cur = kDone;
+                else { --sp; cur = stk[sp * kTravBlock]; }
+            }
+        } else {
+            if (is_ret) {
+                if (busy) done(idx, best, t_max);
+                busy = false;
+                uint32_t cand = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_ret >> 32),
+                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)m_ret, 0u));
+                if (cand < end) {
+                    idx = cand;
+                    fetch(idx, o, d, t_min, t_max);
+                    inv = mk(1. / d.x, 1. / d.y, 1. / d.z);
+                    best = PT_MISS; best_id = PT_MISS;
+                    sp = 0;
+                    cur = sc.n_nodes ? 0 : kDone;
+                    busy = true;
+                }
+            }
+            if (cursor < end) cursor += (uint32_t)n_ret;
+        }
+    }
+}
+
+// The other scheduling of the same work, one ray per lane for its whole life: "while-while" —
+// the wave keeps stepping through inner nodes until every lane holds a leaf (or is done), then all
+// of them test their leaf together.  No bookkeeping per unit of work, so it wins where the rays of
+// a wave are coherent or every ray is short (primary rays: 96 % lane utilisation on CornellBox;
+// scenes under ~500 triangles), and loses by 15-40 % on incoherent rays in deeper trees (measured
+// crossover: DESIGN.md "Traversal scheduling").  Returns leaf-order index / PT_MISS.
 template <int DEPTH, bool ANY, bool STATS>
 __device__ __forceinline__ uint32_t traverse(const Scene& sc, D3 o, D3 d, double t_min, double& t_max, int* stk,
                                              uint32_t& n_nodes, uint32_t& n_tris) {
@@ -241,53 +316,67 @@ __device__ __forceinline__ unsigned long long live_total(const Live& lv) {
 // Consecutive rays stay on one L2 (locality for node/triangle fetches) while every XCD sees the
 // same mix of cheap and expensive regions (a contiguous eighth per XCD left XCDs idle: the ceiling
 // band finishes long before the heightfield band).  Bijective on [0, nb) when nb % (8*kChunk) == 0.
-constexpr uint32_t kChunk = 64;
-__device__ __forceinline__ uint32_t xcd_block(uint32_t b) {
+constexpr uint32_t kChunkRays = 4096;  // wave_rays divides it
+__device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t chunk) {
     uint32_t x = b & 7u, k = b >> 3;
-    return ((k / kChunk) * 8u + x) * kChunk + (k % kChunk);
+    return ((k / chunk) * 8u + x) * chunk + (k % chunk);
 }
-__host__ __device__ __forceinline__ uint32_t trav_blocks(uint32_t n) {  // blocks for n rays, padded to whole chunk rounds
-    uint32_t nb = (n + kTravBlock - 1) / kTravBlock, r = 8u * kChunk;
+__host__ __device__ __forceinline__ uint32_t trav_blocks(uint32_t n, uint32_t wave_rays) {  // blocks for n rays, padded to whole chunk rounds
+    uint32_t nb = (n + wave_rays - 1) / wave_rays, r = 8u * (kChunkRays / wave_rays);
     return (nb + r - 1) / r * r;
 }
 
-// PRIMARY: the generate stage (main.rs:412-427 + scene.rs:37-45) runs in the prologue — lane i is
-// path slot i of the batch and builds its camera ray in registers; nothing is read from the queue.
-template <int DEPTH, bool STATS, bool PRIMARY>
+// PRIMARY: the generate stage (main.rs:412-427 + scene.rs:37-45) runs in the fetch — ray i is path
+// slot i of the batch and its camera ray is built in registers; nothing is read from the queue.
+// One wave per workgroup; workgroup b owns the wave_rays queue entries [b, b+1) * wave_rays.
+template <int DEPTH, bool STATS, bool PRIMARY, bool VOTE>
 __global__ __launch_bounds__(kTravBlock) void k_extend(Scene sc, Frame fr, Queue q, const double* __restrict__ tmin,
-                                                   const double* __restrict__ tmax, Live live, Hits hits,
-                                                   Counters* ctr) {
+                                                   const double* __restrict__ tmax, Live live, uint32_t wave_rays,
+                                                   Hits hits, Counters* ctr) {
     __shared__ int stack[DEPTH * kTravBlock];
     if (ctr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->rays, live_total(live));
-    uint32_t i;
+    uint32_t begin, end;
     if (live.counts) {
         // segmented queue: live entries are already spread evenly over the index range, and the
         // hardware's round-robin block placement spreads them over the XCDs
-        i = blockIdx.x * kTravBlock + threadIdx.x;
-        if (i >= live.n || i >= live_end(live, blockIdx.x * kTravBlock)) return;
+        begin = blockIdx.x * wave_rays;
+        if (begin >= live.n) return;
+        end = min(begin + wave_rays, live_end(live, begin));
     } else {
         // dense queue [0, n): only the first trav_blocks(n) blocks take part, remapped in chunks
-        if (blockIdx.x >= trav_blocks(live.n)) return;
-        i = xcd_block(blockIdx.x) * kTravBlock + threadIdx.x;
-        if (i >= live.n) return;
+        if (blockIdx.x >= trav_blocks(live.n, wave_rays)) return;
+        begin = xcd_block(blockIdx.x, kChunkRays / wave_rays) * wave_rays;
+        end = min(begin + wave_rays, live.n);
     }
-    D3 o, d;
-    if (PRIMARY) {
-        uint32_t s = i / fr.n_tile_pixels, p = i - s * fr.n_tile_pixels;
-        uint32_t ty = p / fr.tile_w, tx = p - ty * fr.tile_w;
-        PixelArgs a = pixel_args(fr.x0 + tx, fr.y0 + ty, fr.width, fr.height, fr.jitter[2 * s], fr.jitter[2 * s + 1]);
-        o = ld3(sc.cam.eye);
-        d = camera_dir(sc.cam, a.x, a.y);
-    } else {
-        o = mk(q.o[0][i], q.o[1][i], q.o[2][i]);
-        d = mk(q.d[0][i], q.d[1][i], q.d[2][i]);
-    }
-    double t_min = tmin ? tmin[i] : 1e-5;                     // ray.rs:21
-    double t_max = tmax ? tmax[i] : 1.7976931348623157e308;   // ray.rs:22 f64::MAX
+    if (begin >= end) return;
     uint32_t nn = 0, nt = 0;
-    uint32_t tri = traverse<DEPTH, false, STATS>(sc, o, d, t_min, t_max, stack + threadIdx.x, nn, nt);
-    hits.tri[i] = tri;
-    hits.t[i] = t_max;
+    auto fetch = [&](uint32_t i, D3& o, D3& d, double& t_min, double& t_max) {
+            if (PRIMARY) {
+                uint32_t s = i / fr.n_tile_pixels, p = i - s * fr.n_tile_pixels;
+                uint32_t ty = p / fr.tile_w, tx = p - ty * fr.tile_w;
+                PixelArgs a = pixel_args(fr.x0 + tx, fr.y0 + ty, fr.width, fr.height, fr.jitter[2 * s], fr.jitter[2 * s + 1]);
+                o = ld3(sc.cam.eye);
+                d = camera_dir(sc.cam, a.x, a.y);
+            } else {
+                o = mk(q.o[0][i], q.o[1][i], q.o[2][i]);
+                d = mk(q.d[0][i], q.d[1][i], q.d[2][i]);
+            }
+            t_min = tmin ? tmin[i] : 1e-5;                    // ray.rs:21
+            t_max = tmax ? tmax[i] : 1.7976931348623157e308;  // ray.rs:22 f64::MAX
+        };
+    auto done = [&](uint32_t i, uint32_t tri, double t) {
+            hits.tri[i] = tri;
+            hits.t[i] = t;
+        };
+    if (VOTE) {
+        trace_range_vote<DEPTH, false, STATS>(sc, begin, end, stack + threadIdx.x, fetch, done, nn, nt);
+    } else if (begin + threadIdx.x < end) {  // wave_rays == 64
+        uint32_t i = begin + threadIdx.x;
+        D3 o, d;
+        double t_min, t_max;
+        fetch(i, o, d, t_min, t_max);
+        done(i, traverse<DEPTH, false, STATS>(sc, o, d, t_min, t_max, stack + threadIdx.x, nn, nt), t_max);
+    }
     if (STATS) {
         // wave-level reduction, one atomic pair per wave
         for (int off = 32; off > 0; off >>= 1) {
@@ -301,22 +390,38 @@ __global__ __launch_bounds__(kTravBlock) void k_extend(Scene sc, Frame fr, Queue
     }
 }
 
-template <int DEPTH>
-__global__ __launch_bounds__(kTravBlock) void k_shadow(Scene sc, ShadowQueue sq, Live live, Sample3 ls, Counters* ctr) {
+template <int DEPTH, bool VOTE>
+__global__ __launch_bounds__(kTravBlock) void k_shadow(Scene sc, ShadowQueue sq, Live live, uint32_t wave_rays, Sample3 ls,
+                                                   Counters* ctr) {
     __shared__ int stack[DEPTH * kTravBlock];
     if (ctr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->shadow_rays, live_total(live));
-    uint32_t i = blockIdx.x * kTravBlock + threadIdx.x;
-    if (i >= live.n || i >= live_end(live, blockIdx.x * kTravBlock)) return;
-    D3 o = mk(sq.o[0][i], sq.o[1][i], sq.o[2][i]);
-    D3 d = mk(sq.d[0][i], sq.d[1][i], sq.d[2][i]);
-    double t_max = sq.tmax[i];
+    uint32_t begin = blockIdx.x * wave_rays;
+    if (begin >= live.n) return;
+    uint32_t end = min(begin + wave_rays, live_end(live, begin));
+    if (begin >= end) return;
     uint32_t nn = 0, nt = 0;
-    uint32_t tri = traverse<DEPTH, true, false>(sc, o, d, 1e-5, t_max, stack + threadIdx.x, nn, nt);
-    if (tri == PT_MISS) {
-        uint32_t slot = sq.slot[i];
-        ls.c[0][slot] += sq.c[0][i];
-        ls.c[1][slot] += sq.c[1][i];
-        ls.c[2][slot] += sq.c[2][i];
+    auto fetch = [&](uint32_t i, D3& o, D3& d, double& t_min, double& t_max) {
+            o = mk(sq.o[0][i], sq.o[1][i], sq.o[2][i]);
+            d = mk(sq.d[0][i], sq.d[1][i], sq.d[2][i]);
+            t_min = 1e-5;
+            t_max = sq.tmax[i];
+        };
+    auto done = [&](uint32_t i, uint32_t tri, double) {
+            if (tri != PT_MISS) return;
+            // unoccluded: the light sample counts (one shadow ray per path slot and launch)
+            uint32_t slot = sq.slot[i];
+            ls.c[0][slot] += sq.c[0][i];
+            ls.c[1][slot] += sq.c[1][i];
+            ls.c[2][slot] += sq.c[2][i];
+        };
+    if (VOTE) {
+        trace_range_vote<DEPTH, true, false>(sc, begin, end, stack + threadIdx.x, fetch, done, nn, nt);
+    } else if (begin + threadIdx.x < end) {  // wave_rays == 64
+        uint32_t i = begin + threadIdx.x;
+        D3 o, d;
+        double t_min, t_max;
+        fetch(i, o, d, t_min, t_max);
+        done(i, traverse<DEPTH, true, false>(sc, o, d, t_min, t_max, stack + threadIdx.x, nn, nt), t_max);
     }
 }
 
@@ -840,13 +945,20 @@ void launch_generate_rays(const Scene& sc, const Frame& fr, double* rays_out, hi
 }
 // The LDS stack is sized for the scene's BVH depth: 8 / 16 / 32 entries per lane (8 / 16 / 32 KB per
 // block), so shallow trees do not pay occupancy for stack they cannot use.
+template <bool STATS, bool PRIMARY, bool VOTE>
+static void launch_extend_v(const Scene& sc, const Frame& fr, Queue q, const double* tmin, const double* tmax, Live live,
+                            uint32_t wr, Hits hits, Counters* ctr, hipStream_t st) {
+    dim3 g(live.counts ? (live.n + wr - 1) / wr : trav_blocks(live.n, wr)), b(kTravBlock);
+    if (sc.bvh_depth <= 8) hipLaunchKernelGGL((k_extend<8, STATS, PRIMARY, VOTE>), g, b, 0, st, sc, fr, q, tmin, tmax, live, wr, hits, ctr);
+    else if (sc.bvh_depth <= 16) hipLaunchKernelGGL((k_extend<16, STATS, PRIMARY, VOTE>), g, b, 0, st, sc, fr, q, tmin, tmax, live, wr, hits, ctr);
+    else hipLaunchKernelGGL((k_extend<32, STATS, PRIMARY, VOTE>), g, b, 0, st, sc, fr, q, tmin, tmax, live, wr, hits, ctr);
+}
 template <bool STATS, bool PRIMARY>
 static void launch_extend_t(const Scene& sc, const Frame& fr, Queue q, const double* tmin, const double* tmax, Live live,
                             Hits hits, Counters* ctr, hipStream_t st) {
-    dim3 g(live.counts ? (live.n + kTravBlock - 1) / kTravBlock : trav_blocks(live.n)), b(kTravBlock);
-    if (sc.bvh_depth <= 8) hipLaunchKernelGGL((k_extend<8, STATS, PRIMARY>), g, b, 0, st, sc, fr, q, tmin, tmax, live, hits, ctr);
-    else if (sc.bvh_depth <= 16) hipLaunchKernelGGL((k_extend<16, STATS, PRIMARY>), g, b, 0, st, sc, fr, q, tmin, tmax, live, hits, ctr);
-    else hipLaunchKernelGGL((k_extend<32, STATS, PRIMARY>), g, b, 0, st, sc, fr, q, tmin, tmax, live, hits, ctr);
+    if (PRIMARY ? sc.vote_primary : sc.vote_secondary)
+        launch_extend_v<STATS, PRIMARY, true>(sc, fr, q, tmin, tmax, live, sc.wave_rays, hits, ctr, st);
+    else launch_extend_v<STATS, PRIMARY, false>(sc, fr, q, tmin, tmax, live, 64, hits, ctr, st);
 }
 void launch_extend(const Scene& sc, Queue q, const double* tmin, const double* tmax, Live live, Hits hits,
                    Counters* ctr, bool stats, hipStream_t st) {
@@ -886,12 +998,17 @@ void launch_shade(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, H
     else if (last) launch_shade_t<false, true>(nee, g, b, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls);
     else launch_shade_t<false, false>(nee, g, b, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls);
 }
+template <bool VOTE>
+static void launch_shadow_v(const Scene& sc, ShadowQueue sq, Live live, uint32_t wr, Sample3 ls, Counters* ctr, hipStream_t st) {
+    dim3 g((live.n + wr - 1) / wr), b(kTravBlock);
+    if (sc.bvh_depth <= 8) hipLaunchKernelGGL((k_shadow<8, VOTE>), g, b, 0, st, sc, sq, live, wr, ls, ctr);
+    else if (sc.bvh_depth <= 16) hipLaunchKernelGGL((k_shadow<16, VOTE>), g, b, 0, st, sc, sq, live, wr, ls, ctr);
+    else hipLaunchKernelGGL((k_shadow<32, VOTE>), g, b, 0, st, sc, sq, live, wr, ls, ctr);
+}
 void launch_shadow(const Scene& sc, ShadowQueue sq, Live live, Sample3 ls, Counters* ctr, hipStream_t st) {
     if (!live.n) return;
-    dim3 g((live.n + kTravBlock - 1) / kTravBlock), b(kTravBlock);
-    if (sc.bvh_depth <= 8) hipLaunchKernelGGL(k_shadow<8>, g, b, 0, st, sc, sq, live, ls, ctr);
-    else if (sc.bvh_depth <= 16) hipLaunchKernelGGL(k_shadow<16>, g, b, 0, st, sc, sq, live, ls, ctr);
-    else hipLaunchKernelGGL(k_shadow<32>, g, b, 0, st, sc, sq, live, ls, ctr);
+    if (sc.vote_shadow) launch_shadow_v<true>(sc, sq, live, sc.wave_rays, ls, ctr, st);
+    else launch_shadow_v<false>(sc, sq, live, 64, ls, ctr, st);
 }
 void launch_accumulate(const Frame& fr, Sample3 ls, double* accum, hipStream_t st) {
     if (!fr.n_tile_pixels) return;

@@ -1,10 +1,13 @@
 #!/bin/bash
-# usage: scripts/gpu_check.sh <tag>  — GPU tests, then both benches; prints a short summary
+# usage: scripts/gpu_check.sh <tag>  — GPU tests, then both benches; prints a short summary.
+# Every GPU step runs under its own time limit and the script ends at the first failing step.
 TAG=$1
-python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/test_$TAG.log 2>&1; echo "tests exit=$?"; tail -3 gpurun_out/test_$TAG.log
-timeout -k 10 300 python bench.py --cpu-seconds 0 > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err || tail -5 gpurun_out/bench_$TAG.err
+timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/test_$TAG.log 2>&1
+rc=$?; echo "tests exit=$rc"; tail -3 gpurun_out/test_$TAG.log
+[ $rc -eq 0 ] || exit $rc
+timeout -k 10 300 python bench.py --cpu-seconds 0 > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err || { tail -5 gpurun_out/bench_$TAG.err; exit 1; }
 python -c "
 import json;d=json.load(open('gpurun_out/bench_$TAG.json'));r=d['roofline'];print('cornell', d['value'],d['ms_per_step'],r['kernel_ms'],r['kernel'],r['achieved'])"
-timeout -k 10 600 python bench.py --scene heightfield --width 3840 --height 2160 --spp 2 --steps 5 --warmup 1 --cpu-seconds 0 > gpurun_out/bench_hf_$TAG.json 2> gpurun_out/bench_hf_$TAG.err || tail -5 gpurun_out/bench_hf_$TAG.err
+timeout -k 10 600 python bench.py --scene heightfield --width 3840 --height 2160 --spp 2 --steps 5 --warmup 1 --cpu-seconds 0 > gpurun_out/bench_hf_$TAG.json 2> gpurun_out/bench_hf_$TAG.err || { tail -5 gpurun_out/bench_hf_$TAG.err; exit 1; }
 python -c "
 import json;d=json.load(open('gpurun_out/bench_hf_$TAG.json'));r=d['roofline'];print('heightfield', d['value'],d['ms_per_step'],r['kernel_ms'],r['kernel'],r['achieved'])"

@@ -226,3 +226,35 @@ def test_caller_supplied_bvh_and_validation(gpu):
     bad.bvh_tri_order = np.zeros_like(order)           # duplicate triangle ids
     with pytest.raises(pt.PtError):
         pt.Scene(bad, gpu)
+
+
+# ---- traversal scheduling: both schedulers (vote-scheduled ranges / one ray per lane) on every scene -----
+FORCE_VOTE = dict(PT_TRAV_VOTE="1", PT_TRAV_VOTE_PRIMARY="1", PT_TRAV_VOTE_SHADOW="1", PT_WAVE_RAYS="128")
+FORCE_LANE = dict(PT_TRAV_VOTE="0", PT_TRAV_VOTE_PRIMARY="0", PT_TRAV_VOTE_SHADOW="0")
+
+
+@pytest.mark.parametrize("wave_rays", ["64", "128", "1024"])
+def test_schedulers_agree_bitwise(gpu, monkeypatch, wave_rays):
+    from pathtracer_amd.synthetic import heightfield_box
+    datas = {name: pt.scene_data(name) for name in ("CornellBox", "Test", "glossy_planes")}
+    datas["heightfield40"] = heightfield_box(cells=40)
+    for name, data in datas.items():
+        made = {}
+        for label, env in (("vote", dict(FORCE_VOTE, PT_WAVE_RAYS=wave_rays)), ("lane", FORCE_LANE)):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            made[label] = pt.Scene(data, gpu)          # the scheduling is resolved at scene creation
+            for k in env:
+                monkeypatch.delenv(k)
+        oracle = O.OracleScene(data)
+        for n in (1, 63, 65, 4099):                    # ragged ranges: below, across and above one wave's range
+            rays = random_rays(data, 4099, seed=n)[:n]
+            rtri, rt = oracle.trace_closest(rays, use_bvh=True)
+            for scene in made.values():
+                tri, t = scene.trace_closest(rays)
+                assert np.array_equal(tri, rtri) and np.array_equal(bits(t), bits(rt)), (name, n)
+        for nee in (False, True):
+            cfg = pt.Config(width=57, height=41, samples_pr_pixel=3, bounces=3, seed=8, nee=nee)
+            a, b = made["vote"].render(cfg), made["lane"].render(cfg)
+            assert a.tobytes() == b.tobytes(), (name, nee)
+            assert a.any()
