@@ -81,45 +81,57 @@ constexpr uint32_t kMaxBounces = 61;
 constexpr uint32_t kCounterSets = kMaxBounces + 3;
 constexpr uint32_t kCounterWords = 2 * kCounterSets * ptd::kSegs;
 
-struct Workspace {
-    DevBuf buf;
-    uint32_t cap_slots = 0;
-    bool nee = false;
+// One batch of frames is traced as one or two "lanes" (sample sub-ranges), each with its own
+// queues, hit records and counters.  Two lanes run on two streams, so that one lane's kernels fill
+// the chip while the other's drain (the vote-scheduled extend has a long tail) and HBM-bound shade
+// work overlaps FP64-bound extend work.  Measured: +6 % on the 10M-triangle scene, -2 % on
+// CornellBox, hence on only for deep trees (pt_scene::pipeline).
+struct Lane {
     ptd::Queue q[2];
     ptd::Hits hits;
     ptd::ShadowQueue sq;
-    ptd::Sample3 ls;
     uint32_t* counters = nullptr;
-    uint32_t seg_size = 0;
+};
+
+struct Workspace {
+    DevBuf buf;
+    uint32_t cap_slots = 0;   // Lsample entries (all lanes together)
+    uint32_t lane_slots = 0;  // path slots per lane
+    int n_lanes = 0;
+    bool nee = false;
+    Lane lane[2];
+    ptd::Sample3 ls;
     DevBuf jitter;
     uint64_t jitter_cap = 0;
 };
 
-void carve_workspace(Workspace& w, void* base, uint32_t n_slots, bool nee, size_t& total) {
+void carve_workspace(Workspace& w, void* base, uint32_t n_slots, uint32_t lane_slots, int n_lanes, bool nee, size_t& total) {
     Carver c(base);
     // queues, hit records and the shadow queue are segmented (ptd::kSegs segments); Lsample is per slot
-    const uint32_t slots = ptd::kSegs * ptd::seg_size_for(n_slots);
-    w.seg_size = ptd::seg_size_for(n_slots);
-    for (int k = 0; k < 2; ++k) {
-        for (int a = 0; a < 3; ++a) w.q[k].o[a] = c.take<double>(slots);
-        for (int a = 0; a < 3; ++a) w.q[k].d[a] = c.take<double>(slots);
-        for (int a = 0; a < 3; ++a) w.q[k].T[a] = c.take<double>(slots);
-        w.q[k].prev_pdf = nee ? c.take<double>(slots) : nullptr;
-        w.q[k].slot = c.take<uint32_t>(slots);
+    const uint32_t slots = ptd::kSegs * ptd::seg_size_for(lane_slots);
+    for (int l = 0; l < n_lanes; ++l) {
+        Lane& ln = w.lane[l];
+        for (int k = 0; k < 2; ++k) {
+            for (int a = 0; a < 3; ++a) ln.q[k].o[a] = c.take<double>(slots);
+            for (int a = 0; a < 3; ++a) ln.q[k].d[a] = c.take<double>(slots);
+            for (int a = 0; a < 3; ++a) ln.q[k].T[a] = c.take<double>(slots);
+            ln.q[k].prev_pdf = nee ? c.take<double>(slots) : nullptr;
+            ln.q[k].slot = c.take<uint32_t>(slots);
+        }
+        ln.hits.tri = c.take<uint32_t>(slots);
+        ln.hits.t = c.take<double>(slots);
+        if (nee) {
+            for (int a = 0; a < 3; ++a) ln.sq.o[a] = c.take<double>(slots);
+            for (int a = 0; a < 3; ++a) ln.sq.d[a] = c.take<double>(slots);
+            ln.sq.tmax = c.take<double>(slots);
+            for (int a = 0; a < 3; ++a) ln.sq.c[a] = c.take<double>(slots);
+            ln.sq.slot = c.take<uint32_t>(slots);
+        } else {
+            std::memset(&ln.sq, 0, sizeof ln.sq);
+        }
+        ln.counters = c.take<uint32_t>(kCounterWords);
     }
-    w.hits.tri = c.take<uint32_t>(slots);
-    w.hits.t = c.take<double>(slots);
     for (int a = 0; a < 3; ++a) w.ls.c[a] = c.take<double>(n_slots);
-    if (nee) {
-        for (int a = 0; a < 3; ++a) w.sq.o[a] = c.take<double>(slots);
-        for (int a = 0; a < 3; ++a) w.sq.d[a] = c.take<double>(slots);
-        w.sq.tmax = c.take<double>(slots);
-        for (int a = 0; a < 3; ++a) w.sq.c[a] = c.take<double>(slots);
-        w.sq.slot = c.take<uint32_t>(slots);
-    } else {
-        std::memset(&w.sq, 0, sizeof w.sq);
-    }
-    w.counters = c.take<uint32_t>(kCounterWords);
     total = c.off;
 }
 
@@ -145,7 +157,12 @@ struct pt_scene {
     pt_stats stats{};
     std::vector<TimedLaunch> timed;
     std::vector<hipEvent_t> event_pool;
+    int pipeline = 0;               // 0: one lane; 1: two lanes on two streams (see Lane)
+    hipStream_t side = nullptr;     // the second lane's stream
+    std::vector<hipEvent_t> sync;   // cross-stream ordering events (no timing)
     ~pt_scene() {
+        if (side) (void)hipStreamDestroy(side);
+        for (auto e : sync) (void)hipEventDestroy(e);
         for (auto* b : d_texels) delete b;
         for (auto e : event_pool) (void)hipEventDestroy(e);
         for (auto& t : timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -194,23 +211,38 @@ int upload(DevBuf& b, const T* src, size_t n) {
     return PT_OK;
 }
 
-int ensure_workspace(pt_scene* s, uint32_t slots, bool nee) {
+int ensure_workspace(pt_scene* s, uint32_t slots, uint32_t lane_slots, int n_lanes, bool nee) {
     Workspace& w = s->ws;
-    if (w.buf.p && w.cap_slots >= slots && (w.nee || !nee)) return PT_OK;
+    if (w.buf.p && w.cap_slots >= slots && w.lane_slots >= lane_slots && w.n_lanes >= n_lanes && (w.nee || !nee))
+        return PT_OK;
     HIP_TRY(hipDeviceSynchronize());
     w.buf.release();
+    w.cap_slots = 0;
     size_t total = 0;
     Workspace probe;
-    carve_workspace(probe, nullptr, slots, nee, total);
+    carve_workspace(probe, nullptr, slots, lane_slots, n_lanes, nee, total);
     hipError_t e = w.buf.alloc(total);
     if (e != hipSuccess) {
-        w.cap_slots = 0;
         set_error("workspace allocation of %zu bytes failed: %s", total, hipGetErrorString(e));
         return PT_ERR_NOMEM;
     }
-    carve_workspace(w, w.buf.p, slots, nee, total);
+    carve_workspace(w, w.buf.p, slots, lane_slots, n_lanes, nee, total);
     w.cap_slots = slots;
+    w.lane_slots = lane_slots;
+    w.n_lanes = n_lanes;
     w.nee = nee;
+    return PT_OK;
+}
+
+constexpr uint64_t kMinLanePaths = 1u << 20;  // below this a lane cannot fill 256 CUs; keep one lane
+
+int ensure_side_stream(pt_scene* s, size_t n_events) {
+    if (!s->side) HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+    while (s->sync.size() < n_events) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        s->sync.push_back(e);
+    }
     return PT_OK;
 }
 
@@ -451,6 +483,8 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
     dv.n_lights = (uint32_t)lights.size();
     dv.bvh_depth = s->depth;
     resolve_scheduling(dv);
+    s->pipeline = dv.bvh_depth > 8;
+    if (const char* e = getenv("PT_PIPELINE")) s->pipeline = atoi(e) != 0;  // tuning / tests, like the above
     dv.plain = 1;
     for (uint32_t i = 0; i < d->n_mats; ++i)
         if (d->mats[i].kind != PT_MAT_LAMBERT || d->mats[i].tex >= 0) dv.plain = 0;
@@ -539,8 +573,12 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
     spp = std::min(spp, P->sample_count);
     spp = std::min<uint32_t>(spp, std::max<uint32_t>(1u, (1u << 30) / npix));
     const uint32_t slots = spp * npix;
-    if ((rc = ensure_workspace(s, slots, nee)) != PT_OK) return rc;
+    // two lanes when a batch has frames to split and enough paths for each half to fill the chip
+    const bool two = s->pipeline != 0 && spp >= 2 && (uint64_t)(spp / 2) * npix >= kMinLanePaths;
+    const uint32_t lane_spp = two ? spp - spp / 2 : spp;
+    if ((rc = ensure_workspace(s, slots, lane_spp * npix, two ? 2 : 1, nee)) != PT_OK) return rc;
     Workspace& w = s->ws;
+    if (two && (rc = ensure_side_stream(s, 2)) != PT_OK) return rc;
     if (w.jitter_cap < P->sample_count) {
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(w.jitter.alloc((size_t)P->sample_count * 2 * sizeof(double)));
@@ -551,6 +589,40 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
                        w.jitter.as<double>(), st);
     const bool stats = s->profiling >= 2;
     ptd::Counters* ctr = s->d_ctr.as<ptd::Counters>();
+
+    struct LaneRun {  // one lane's share of the batch
+        Lane* ln;
+        hipStream_t st;
+        ptd::Frame fr;
+        ptd::Sample3 ls;
+        uint32_t n_max, seg, cap;
+    };
+    // one bounce of one lane, split in its two phases
+    auto run_extend = [&](LaneRun& r, uint32_t bounce) {
+        ptd::Live live = bounce == 0 ? ptd::Live{nullptr, 0, r.n_max}
+                                     : ptd::Live{r.ln->counters + bounce * ptd::kSegs, r.seg, r.cap};
+        Timer t(s, r.st, PT_K_EXTEND);
+        // bounce 0 runs over the dense slot range; later bounces over the segmented queue
+        if (bounce == 0) ptd::launch_extend_primary(s->dev, r.fr, r.ln->hits, ctr, stats, r.st);
+        else ptd::launch_extend(s->dev, r.ln->q[bounce & 1], nullptr, nullptr, live, r.ln->hits, ctr, stats, r.st);
+    };
+    auto run_shade = [&](LaneRun& r, uint32_t bounce) {
+        uint32_t* path_cnt = r.ln->counters;
+        uint32_t* shad_cnt = r.ln->counters + kCounterSets * ptd::kSegs;
+        ptd::Live live = bounce == 0 ? ptd::Live{nullptr, 0, r.n_max}
+                                     : ptd::Live{path_cnt + bounce * ptd::kSegs, r.seg, r.cap};
+        ptd::Push push{path_cnt + (bounce + 1) * ptd::kSegs, r.seg};
+        ptd::Push spush{shad_cnt + bounce * ptd::kSegs, r.seg};
+        {
+            Timer t(s, r.st, PT_K_SHADE);
+            ptd::launch_shade(s->dev, r.fr, bounce, r.ln->q[bounce & 1], r.ln->hits, live, r.ln->q[(bounce + 1) & 1],
+                              push, r.ln->sq, spush, r.ls, r.st);
+        }
+        if (nee && bounce < P->max_bounces) {
+            Timer t(s, r.st, PT_K_SHADOW);
+            ptd::launch_shadow(s->dev, r.ln->sq, ptd::Live{spush.counts, r.seg, r.cap}, r.ls, ctr, r.st);
+        }
+    };
 
     for (uint32_t b0 = 0; b0 < P->sample_count; b0 += spp) {
         const uint32_t ns = std::min(spp, P->sample_count - b0);
@@ -564,35 +636,49 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
         fr.max_bounces = P->max_bounces;
         fr.flags = P->flags;
         fr.jitter = w.jitter.as<double>() + (size_t)b0 * 2;
-        const uint32_t n_max = ns * npix;
-        HIP_TRY(hipMemsetAsync(w.counters, 0, kCounterWords * sizeof(uint32_t), st));
         // the generate stage is fused into the bounce-0 extend and shade kernels (they rebuild the
         // camera ray from the pixel): no primary-ray queue is written or read.
-        const uint32_t seg = ptd::seg_size_for(n_max);  // <= w.seg_size: the workspace was carved for >= n_max slots
-        const uint32_t cap = ptd::kSegs * seg;
-        uint32_t* path_cnt = w.counters;
-        uint32_t* shad_cnt = w.counters + kCounterSets * ptd::kSegs;
-        for (uint32_t bounce = 0; bounce <= P->max_bounces; ++bounce) {
-            // bounce 0 runs over the dense slot range; later bounces over the segmented queue
-            ptd::Live live = bounce == 0 ? ptd::Live{nullptr, 0, n_max}
-                                         : ptd::Live{path_cnt + bounce * ptd::kSegs, seg, cap};
-            ptd::Push push{path_cnt + (bounce + 1) * ptd::kSegs, seg};
-            ptd::Push spush{shad_cnt + bounce * ptd::kSegs, seg};
-            ptd::Queue& qin = w.q[bounce & 1];
-            ptd::Queue& qout = w.q[(bounce + 1) & 1];
-            {
-                Timer t(s, st, PT_K_EXTEND);
-                if (bounce == 0) ptd::launch_extend_primary(s->dev, fr, w.hits, ctr, stats, st);
-                else ptd::launch_extend(s->dev, qin, nullptr, nullptr, live, w.hits, ctr, stats, st);
+        const int n_run = (two && ns >= 2) ? 2 : 1;
+        LaneRun run[2];
+        for (int l = 0; l < n_run; ++l) {
+            LaneRun& r = run[l];
+            const uint32_t s0 = l == 0 ? 0 : ns - ns / 2, s1 = (n_run == 2 && l == 0) ? ns - ns / 2 : ns;
+            r.ln = &w.lane[l];
+            r.st = l == 0 ? st : s->side;
+            r.fr = fr;
+            r.fr.n_samples = s1 - s0;
+            r.fr.sample_base = fr.sample_base + s0;
+            r.fr.jitter = fr.jitter + (size_t)s0 * 2;
+            for (int a = 0; a < 3; ++a) r.ls.c[a] = w.ls.c[a] + (size_t)s0 * npix;
+            r.n_max = (s1 - s0) * npix;
+            r.seg = ptd::seg_size_for(r.n_max);  // <= the size the lane was carved for
+            r.cap = ptd::kSegs * r.seg;
+        }
+        if (n_run == 1) {
+            HIP_TRY(hipMemsetAsync(run[0].ln->counters, 0, kCounterWords * sizeof(uint32_t), st));
+            for (uint32_t bounce = 0; bounce <= P->max_bounces; ++bounce) {
+                run_extend(run[0], bounce);
+                run_shade(run[0], bounce);
             }
-            {
-                Timer t(s, st, PT_K_SHADE);
-                ptd::launch_shade(s->dev, fr, bounce, qin, w.hits, live, qout, push, w.sq, spush, w.ls, st);
+        } else {
+            // The two lanes run free on their streams between a fork and a join.  Forcing them into
+            // anti-phase with per-bounce events (extend of one lane beside shade of the other) was
+            // measured slower than one lane on both bench scenes: the workgroup dispatcher already
+            // interleaves whatever the two queues hold.
+            hipStream_t sd = s->side;
+            hipEvent_t* ev = s->sync.data();
+            HIP_TRY(hipEventRecord(ev[0], st));  // fork: the side stream starts after everything queued so far
+            HIP_TRY(hipStreamWaitEvent(sd, ev[0], 0));
+            HIP_TRY(hipMemsetAsync(run[0].ln->counters, 0, kCounterWords * sizeof(uint32_t), st));
+            HIP_TRY(hipMemsetAsync(run[1].ln->counters, 0, kCounterWords * sizeof(uint32_t), sd));
+            for (uint32_t bounce = 0; bounce <= P->max_bounces; ++bounce) {
+                run_extend(run[0], bounce);
+                run_extend(run[1], bounce);
+                run_shade(run[0], bounce);
+                run_shade(run[1], bounce);
             }
-            if (nee && bounce < P->max_bounces) {
-                Timer t(s, st, PT_K_SHADOW);
-                ptd::launch_shadow(s->dev, w.sq, ptd::Live{spush.counts, seg, cap}, w.ls, ctr, st);
-            }
+            HIP_TRY(hipEventRecord(ev[1], sd));  // join
+            HIP_TRY(hipStreamWaitEvent(st, ev[1], 0));
         }
         {
             Timer t(s, st, PT_K_ACCUMULATE);

@@ -950,7 +950,7 @@ static void launch_extend_v(const Scene& sc, const Frame& fr, Queue q, const dou
                             uint32_t wr, Hits hits, Counters* ctr, hipStream_t st) {
     dim3 g(live.counts ? (live.n + wr - 1) / wr : trav_blocks(live.n, wr)), b(kTravBlock);
     if (sc.bvh_depth <= 8) hipLaunchKernelGGL((k_extend<8, STATS, PRIMARY, VOTE>), g, b, 0, st, sc, fr, q, tmin, tmax, live, wr, hits, ctr);
-    else if (sc.bvh_depth <= 16) hipLaunchKernelGGL((k_extend<16, STATS, PRIMARY, VOTE>), g, b, 0, st, sc, fr, q, tmin, tmax, live, wr, hits, ctr);
+    else if (sc.bvh_depth <= 16 || getenv("PT_HACK16")) hipLaunchKernelGGL((k_extend<16, STATS, PRIMARY, VOTE>), g, b, 0, st, sc, fr, q, tmin, tmax, live, wr, hits, ctr);
     else hipLaunchKernelGGL((k_extend<32, STATS, PRIMARY, VOTE>), g, b, 0, st, sc, fr, q, tmin, tmax, live, wr, hits, ctr);
 }
 template <bool STATS, bool PRIMARY>

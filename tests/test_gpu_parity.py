@@ -258,3 +258,25 @@ def test_schedulers_agree_bitwise(gpu, monkeypatch, wave_rays):
             a, b = made["vote"].render(cfg), made["lane"].render(cfg)
             assert a.tobytes() == b.tobytes(), (name, nee)
             assert a.any()
+
+
+@pytest.mark.parametrize("nee", [False, True])
+def test_two_lane_pipeline_is_bitwise_invariant(gpu, monkeypatch, nee):
+    # batches of >= 2 frames and >= 2^20 paths per half run as two lanes on two streams; the image
+    # must not depend on it (same per-path arithmetic, same accumulation order)
+    data = pt.scene_data("CornellBox")
+    monkeypatch.setenv("PT_PIPELINE", "0")
+    one = pt.Scene(data, gpu)
+    monkeypatch.setenv("PT_PIPELINE", "1")
+    two = pt.Scene(data, gpu)
+    monkeypatch.delenv("PT_PIPELINE")
+    cfg = pt.Config(width=1024, height=1024, samples_pr_pixel=5, bounces=2, seed=6, nee=nee, spp_per_batch=3)
+    a, b = one.render(cfg), two.render(cfg)          # batches of 3 (lanes of 2 + 1) and 2 (1 + 1) frames
+    assert a.tobytes() == b.tobytes()
+    small = pt.Config(dim=64, samples_pr_pixel=4, seed=6, nee=nee)   # too small to split: one lane either way
+    assert one.render(small).tobytes() == two.render(small).tobytes()
+    oracle = O.OracleScene(data)
+    cfg1 = pt.Config(width=1024, height=1024, samples_pr_pixel=2, bounces=2, seed=6, nee=nee)
+    ref = oracle.render(cfg1, threads=16)
+    img = two.render(cfg1)
+    assert (np.abs(img - ref) > 1e-9 * np.maximum(1.0, np.abs(ref))).mean() < 1e-3
