@@ -123,39 +123,70 @@ def main():
         rays2 = max(1, st2["rays"])
         V = st2["nodes_visited"] / rays2
         T = st2["tris_tested"] / rays2
-        # SURVEY.md §8d per-ray figure: B_ray = 32 V + 36 T + 128.  The 128 B queue record always
-        # crosses HBM; the 32 V + 36 T scene bytes do only when the scene does not fit the caches
-        # (config 5).  For a cache-resident scene they are L2/L1-served and priced separately.
+        # Algorithmic bytes (DESIGN.md "Measurement").  SURVEY.md §8d prices a ray at
+        # B_ray = 32 V + 36 T + 128: V child boxes (32 B each), T triangles (36 B) and one path
+        # record written by the producer and read by the consumer.  Per kernel, with this build's
+        # records (path record 76 B = o, d, T as f64 + slot, +8 B pdf with NEE; hit record 12 B):
+        #   extend      primary ray: 12 written; secondary ray: 48 read + 12 written
+        #   shade       per ray 12 read; secondary ray: +76 read; per continuing path 76 written;
+        #               per sample 24 written (Lsample)
+        #   path        (extend+shade fused) secondary ray: 76 read; continuing path: 76 written;
+        #               per sample 24 written
+        #   accumulate  per sample 24 read, per pixel and launch 48 (accum read-modify-write)
+        # The scene terms 32 V + 36 T are added to the traversing kernel only when the scene does
+        # not fit one XCD's L2 (config 5); for a cache-resident scene they are reported as L2-served.
         scene_bytes = data.n_tris * 48 + len(scene.bvh()[0]) * 64
         resident = scene_bytes < (4 << 20)  # one XCD's L2
         scene_ray = 32.0 * V + 36.0 * T
-        b_ray_hbm = 128.0 + (0.0 if resident else scene_ray)
-        b_ray = 128.0 + scene_ray
-        rays_per_sample = st["rays"] / max(1, samples_per_rank)
+        rec, hit = 76.0, 12.0
+        P = float(samples_per_rank)                 # primary rays of the timed region
+        S = max(0.0, float(st["rays"]) - P)         # secondary rays == records written
+        scene_all = float(st["rays"]) * scene_ray
+        per_kind = {
+            "extend": P * hit + S * (48.0 + hit),
+            "shade": (P + S) * hit + S * rec + S * rec + P * 24.0,
+            "path": S * rec + S * rec + P * 24.0,
+            "accumulate": P * 24.0 + float(npix) * 48.0 * max(1, kern["accumulate"]["launches"]),
+            "shadow": float(st["shadow_rays"]) * (56.0 + 24.0 + 4.0),
+            "generate": 0.0,
+        }
+        trav = "path" if kern["path"]["ms"] > kern["extend"]["ms"] else "extend"
         launches = max(1, kern[dom]["launches"])
         avg_ms = kern[dom]["ms"] / launches
-        if dom in ("extend", "shadow"):
-            units = st["rays"] / max(1, kern["extend"]["launches"])  # rays per extend launch
-            bytes_per_launch, all_bytes = units * b_ray_hbm, units * b_ray
-        else:
-            units = samples_per_rank / launches
-            bytes_per_launch = units * (rays_per_sample * b_ray_hbm + 24.0)
-            all_bytes = units * (rays_per_sample * b_ray + 24.0)
+        hbm_bytes = per_kind[dom] + (scene_all if (dom == trav and not resident) else 0.0)
+        l2_bytes = scene_all if (dom == trav and resident) else 0.0
+        bytes_per_launch = hbm_bytes / launches
         gbs = lambda b, ms: b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         achieved = gbs(bytes_per_launch, avg_ms)
-        b_sample = rays_per_sample * b_ray_hbm + 24.0
+        whole = sum(per_kind[k] for k in kern if kern[k]["launches"]) + (0.0 if resident else scene_all)
+        # HBM traffic per launch of the dominant kernel from the rocprofv3 PMC passes of this same
+        # command (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE; profiles/traffic.json, scripts/pmc_traffic.py)
+        traffic, pmc = None, {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                tj = json.load(f)
+            key = f"{args.scene}_{args.width}x{args.height}_spp{args.spp}_b{args.bounces}"
+            pmc = tj.get(key, {}).get(dom, {})
+            traffic = pmc.get("traffic_bytes_per_launch")
+        except (OSError, ValueError):
+            pass
         roofline = {
             "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+            # from the committed rocprofv3 PMC passes of this command (profiles/traffic.json), not live:
+            "pmc": {k: pmc.get(k) for k in ("valu_busy", "lane_utilisation", "waves_per_simd", "l2_hit")} if pmc else None,
             "avg_launch_ms": round(avg_ms, 4), "launches": launches,
             "algorithmic_bytes_per_launch": round(bytes_per_launch),
             "scene_cache_resident": resident, "scene_bytes": scene_bytes,
-            "l2_served_GBs": round(gbs(all_bytes - bytes_per_launch, avg_ms), 2) if resident else 0.0,
+            "l2_served_GBs": round(gbs(l2_bytes / launches, avg_ms), 2),
             "nodes_per_ray": round(V, 3), "tris_per_ray": round(T, 3),
-            "bytes_per_ray_hbm": round(b_ray_hbm, 1), "bytes_per_ray_with_scene": round(b_ray, 1),
+            "rays_per_sample": round(st["rays"] / max(1, samples_per_rank), 4),
             "kernel_ms": {k: round(v["ms"], 3) for k, v in kern.items()},
+            "kernel_launches": {k: v["launches"] for k, v in kern.items()},
             "kernel_share": {k: round(v["ms"] / total_kernel_ms, 4) for k, v in kern.items()} if total_kernel_ms else {},
-            "whole_path_GBs": round(gbs(b_sample * samples_per_rank, total_kernel_ms), 2),
+            "kernel_GBs": {k: round(gbs(per_kind[k] + (scene_all if (k == trav and not resident) else 0.0), v["ms"]), 1)
+                           for k, v in kern.items() if v["launches"]},
+            "whole_path_GBs": round(gbs(whole, total_kernel_ms), 2),
         }
         # ---- CPU baseline: the oracle (C++ restatement, libm, f64) on this box's host cores ----
         cpu = None

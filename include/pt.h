@@ -136,8 +136,10 @@ typedef struct pt_kernel_stat {
     double ms; /* summed HIP-event time */
 } pt_kernel_stat;
 
-/* PT_K_GENERATE stays 0 in renders: the stage is fused into the bounce-0 extend/shade kernels */
-enum { PT_K_GENERATE = 0, PT_K_EXTEND, PT_K_SHADE, PT_K_SHADOW, PT_K_ACCUMULATE, PT_K_COUNT };
+/* PT_K_GENERATE stays 0 in renders: the stage is fused into the bounce-0 kernels.  PT_K_PATH is
+ * the fused extend+shade kernel of one bounce (scenes whose rays are traced one per lane); a render
+ * reports each bounce under either PT_K_PATH or PT_K_EXTEND + PT_K_SHADE. */
+enum { PT_K_GENERATE = 0, PT_K_EXTEND, PT_K_SHADE, PT_K_SHADOW, PT_K_ACCUMULATE, PT_K_PATH, PT_K_COUNT };
 
 typedef struct pt_stats {
     uint64_t samples;        /* render() calls (main.rs:283) */

@@ -18,8 +18,8 @@ PT_MAT_LAMBERT, PT_MAT_GLOSSY = 0, 1
 PT_BVH_EMPTY = 0x7FFFFFFF
 PT_FLAG_USE_DIFFS, PT_FLAG_NEE, PT_FLAG_DROP_NONFINITE = 1, 2, 4
 PT_LOAD_GLOSSY, PT_LOAD_TEXTURES = 1, 2
-PT_K_GENERATE, PT_K_EXTEND, PT_K_SHADE, PT_K_SHADOW, PT_K_ACCUMULATE, PT_K_COUNT = 0, 1, 2, 3, 4, 5
-KERNEL_NAMES = ("generate", "extend", "shade", "shadow", "accumulate")
+PT_K_GENERATE, PT_K_EXTEND, PT_K_SHADE, PT_K_SHADOW, PT_K_ACCUMULATE, PT_K_PATH, PT_K_COUNT = 0, 1, 2, 3, 4, 5, 6
+KERNEL_NAMES = ("generate", "extend", "shade", "shadow", "accumulate", "path")
 
 
 class pt_material(C.Structure):

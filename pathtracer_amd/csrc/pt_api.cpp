@@ -197,6 +197,7 @@ void resolve_scheduling(ptd::Scene& dv) {
     dv.vote_primary = flag("PT_TRAV_VOTE_PRIMARY", false);
     dv.vote_secondary = flag("PT_TRAV_VOTE", deep);
     dv.vote_shadow = flag("PT_TRAV_VOTE_SHADOW", deep);
+    dv.fuse = flag("PT_FUSE", true);
     dv.wave_rays = 256;
     if (const char* e = getenv("PT_WAVE_RAYS")) {
         uint32_t r = (uint32_t)atoi(e);
@@ -590,6 +591,9 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
     const bool stats = s->profiling >= 2;
     ptd::Counters* ctr = s->d_ctr.as<ptd::Counters>();
 
+    // a bounce runs as the fused path kernel where one exists; the node/triangle counters of
+    // profiling level 2 live in the extend kernel, so that level keeps the two-kernel form
+    auto can_fuse = [&](uint32_t bounce) { return !stats && ptd::path_fusable(s->dev, bounce); };
     struct LaneRun {  // one lane's share of the batch
         Lane* ln;
         hipStream_t st;
@@ -606,14 +610,18 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
         if (bounce == 0) ptd::launch_extend_primary(s->dev, r.fr, r.ln->hits, ctr, stats, r.st);
         else ptd::launch_extend(s->dev, r.ln->q[bounce & 1], nullptr, nullptr, live, r.ln->hits, ctr, stats, r.st);
     };
-    auto run_shade = [&](LaneRun& r, uint32_t bounce) {
+    auto run_shade = [&](LaneRun& r, uint32_t bounce, bool fused) {
         uint32_t* path_cnt = r.ln->counters;
         uint32_t* shad_cnt = r.ln->counters + kCounterSets * ptd::kSegs;
         ptd::Live live = bounce == 0 ? ptd::Live{nullptr, 0, r.n_max}
                                      : ptd::Live{path_cnt + bounce * ptd::kSegs, r.seg, r.cap};
         ptd::Push push{path_cnt + (bounce + 1) * ptd::kSegs, r.seg};
         ptd::Push spush{shad_cnt + bounce * ptd::kSegs, r.seg};
-        {
+        if (fused) {  // extend + shade in one kernel: nothing was launched by run_extend
+            Timer t(s, r.st, PT_K_PATH);
+            ptd::launch_path(s->dev, r.fr, bounce, r.ln->q[bounce & 1], live, r.ln->q[(bounce + 1) & 1], push, r.ln->sq,
+                             spush, r.ls, ctr, r.st);
+        } else {
             Timer t(s, r.st, PT_K_SHADE);
             ptd::launch_shade(s->dev, r.fr, bounce, r.ln->q[bounce & 1], r.ln->hits, live, r.ln->q[(bounce + 1) & 1],
                               push, r.ln->sq, spush, r.ls, r.st);
@@ -657,8 +665,9 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
         if (n_run == 1) {
             HIP_TRY(hipMemsetAsync(run[0].ln->counters, 0, kCounterWords * sizeof(uint32_t), st));
             for (uint32_t bounce = 0; bounce <= P->max_bounces; ++bounce) {
-                run_extend(run[0], bounce);
-                run_shade(run[0], bounce);
+                const bool fused = can_fuse(bounce);
+                if (!fused) run_extend(run[0], bounce);
+                run_shade(run[0], bounce, fused);
             }
         } else {
             // The two lanes run free on their streams between a fork and a join.  Forcing them into
@@ -672,10 +681,11 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
             HIP_TRY(hipMemsetAsync(run[0].ln->counters, 0, kCounterWords * sizeof(uint32_t), st));
             HIP_TRY(hipMemsetAsync(run[1].ln->counters, 0, kCounterWords * sizeof(uint32_t), sd));
             for (uint32_t bounce = 0; bounce <= P->max_bounces; ++bounce) {
-                run_extend(run[0], bounce);
-                run_extend(run[1], bounce);
-                run_shade(run[0], bounce);
-                run_shade(run[1], bounce);
+                const bool fused = can_fuse(bounce);
+                if (!fused) run_extend(run[0], bounce);
+                if (!fused) run_extend(run[1], bounce);
+                run_shade(run[0], bounce, fused);
+                run_shade(run[1], bounce, fused);
             }
             HIP_TRY(hipEventRecord(ev[1], sd));  // join
             HIP_TRY(hipStreamWaitEvent(st, ev[1], 0));

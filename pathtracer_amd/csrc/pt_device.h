@@ -59,6 +59,7 @@ struct Scene {
     // traversal scheduling, resolved at scene creation (pt_api.cpp resolve_scheduling): vote-
     // scheduled ranges of wave_rays rays per wave, or one ray per lane
     uint8_t vote_primary, vote_secondary, vote_shadow;
+    uint8_t fuse;  // extend + shade of a bounce in one kernel where its rays go one per lane
     uint32_t wave_rays;
     uint32_t pad;
     Camera cam;
@@ -145,6 +146,11 @@ void launch_extend_primary(const Scene& sc, const Frame& fr, Hits hits, Counters
 void launch_shade(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, Hits hits, Live live, Queue out,
                   Push out_push, ShadowQueue sq, Push sq_push, Sample3 lsample, hipStream_t st);
 void launch_shadow(const Scene& sc, ShadowQueue sq, Live live, Sample3 lsample, Counters* ctr, hipStream_t st);
+// fused extend + shade of one bounce; false if this scene / bounce has no fused form (caller then
+// launches extend and shade)
+bool path_fusable(const Scene& sc, uint32_t bounce);
+bool launch_path(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, Live live, Queue out, Push out_push,
+                 ShadowQueue sq, Push sq_push, Sample3 lsample, Counters* ctr, hipStream_t st);
 void launch_accumulate(const Frame& fr, Sample3 lsample, double* accum, hipStream_t st);
 // parity entry points
 void launch_leaf_to_global(const Scene& sc, uint32_t* tri, uint32_t n, hipStream_t st);

@@ -157,7 +157,7 @@ __device__ __forceinline__ bool slab(double lox, double loy, double loz, double 
 // or pop.  kDone marks an empty stack; it is negative like a leaf reference but decodes to a
 // triangle offset >= 2^28, which no scene has.
 constexpr int kDone = (int)0x80000000;
-template <int DEPTH, bool STATS>
+template <int DEPTH, bool STATS, int STRIDE = kTravBlock>
 __device__ __forceinline__ int node_step(const Scene& sc, int cur, D3 o, D3 inv, double t_min, double t_max, int* stk,
                                          int& sp, uint32_t& n_nodes) {
     const float4* np = sc.nodes + (size_t)cur * 4;
@@ -172,14 +172,14 @@ __device__ __forceinline__ int node_step(const Scene& sc, int cur, D3 o, D3 inv,
     if (h0 && h1) {
         int nearc = c0, farc = c1;
         if (tn1 < tn0) { nearc = c1; farc = c0; }
-        if (sp < DEPTH) { stk[sp * kTravBlock] = farc; ++sp; }
+        if (sp < DEPTH) { stk[sp * STRIDE] = farc; ++sp; }
         return nearc;
     }
     if (h0) return c0;
     if (h1) return c1;
     if (sp == 0) return kDone;
     --sp;
-    return stk[sp * kTravBlock];
+    return stk[sp * STRIDE];
 }
 
 // BVH traversal of the rays [begin, end) by one wave, stack in LDS laid out [entry][lane]
@@ -262,7 +262,7 @@ __device__ __forceinline__ void trace_range_vote(const Scene& sc, uint32_t begin
 // a wave are coherent or every ray is short (primary rays: 96 % lane utilisation on CornellBox;
 // scenes under ~500 triangles), and loses by 15-40 % on incoherent rays in deeper trees (measured
 // crossover: DESIGN.md "Traversal scheduling").  Returns leaf-order index / PT_MISS.
-template <int DEPTH, bool ANY, bool STATS>
+template <int DEPTH, bool ANY, bool STATS, int STRIDE = kTravBlock>
 __device__ __forceinline__ uint32_t traverse(const Scene& sc, D3 o, D3 d, double t_min, double& t_max, int* stk,
                                              uint32_t& n_nodes, uint32_t& n_tris) {
     uint32_t best = PT_MISS, best_id = PT_MISS;
@@ -271,7 +271,7 @@ __device__ __forceinline__ uint32_t traverse(const Scene& sc, D3 o, D3 d, double
     int sp = 0;
     int cur = 0;
     while (cur != kDone) {
-        while (cur >= 0) cur = node_step<DEPTH, STATS>(sc, cur, o, inv, t_min, t_max, stk, sp, n_nodes);
+        while (cur >= 0) cur = node_step<DEPTH, STATS, STRIDE>(sc, cur, o, inv, t_min, t_max, stk, sp, n_nodes);
         if (cur == kDone) break;
         int code = ~cur;
         uint32_t first = (uint32_t)code >> 3, cnt = ((uint32_t)code & 7u) + 1u;
@@ -291,7 +291,7 @@ __device__ __forceinline__ uint32_t traverse(const Scene& sc, D3 o, D3 d, double
         }
         if (sp == 0) break;
         --sp;
-        cur = stk[sp * kTravBlock];
+        cur = stk[sp * STRIDE];
     }
     return best;
 }
@@ -335,17 +335,20 @@ __global__ __launch_bounds__(kTravBlock) void k_extend(Scene sc, Frame fr, Queue
                                                    Hits hits, Counters* ctr) {
     __shared__ int stack[DEPTH * kTravBlock];
     if (ctr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->rays, live_total(live));
+    // wave w of the launch owns the wave_rays queue entries [w, w + 1) * wave_rays
+    const uint32_t wib = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t block_rays = wave_rays * (kTravBlock / 64);
     uint32_t begin, end;
     if (live.counts) {
         // segmented queue: live entries are already spread evenly over the index range, and the
         // hardware's round-robin block placement spreads them over the XCDs
-        begin = blockIdx.x * wave_rays;
+        begin = blockIdx.x * block_rays + wib * wave_rays;
         if (begin >= live.n) return;
         end = min(begin + wave_rays, live_end(live, begin));
     } else {
         // dense queue [0, n): only the first trav_blocks(n) blocks take part, remapped in chunks
-        if (blockIdx.x >= trav_blocks(live.n, wave_rays)) return;
-        begin = xcd_block(blockIdx.x, kChunkRays / wave_rays) * wave_rays;
+        if (blockIdx.x >= trav_blocks(live.n, block_rays)) return;
+        begin = xcd_block(blockIdx.x, kChunkRays / block_rays) * block_rays + wib * wave_rays;
         end = min(begin + wave_rays, live.n);
     }
     if (begin >= end) return;
@@ -370,8 +373,8 @@ __global__ __launch_bounds__(kTravBlock) void k_extend(Scene sc, Frame fr, Queue
         };
     if (VOTE) {
         trace_range_vote<DEPTH, false, STATS>(sc, begin, end, stack + threadIdx.x, fetch, done, nn, nt);
-    } else if (begin + threadIdx.x < end) {  // wave_rays == 64
-        uint32_t i = begin + threadIdx.x;
+    } else if (begin + lane < end) {  // wave_rays == 64
+        uint32_t i = begin + lane;
         D3 o, d;
         double t_min, t_max;
         fetch(i, o, d, t_min, t_max);
@@ -395,7 +398,8 @@ __global__ __launch_bounds__(kTravBlock) void k_shadow(Scene sc, ShadowQueue sq,
                                                    Counters* ctr) {
     __shared__ int stack[DEPTH * kTravBlock];
     if (ctr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->shadow_rays, live_total(live));
-    uint32_t begin = blockIdx.x * wave_rays;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t begin = (blockIdx.x * (kTravBlock / 64) + (threadIdx.x >> 6)) * wave_rays;
     if (begin >= live.n) return;
     uint32_t end = min(begin + wave_rays, live_end(live, begin));
     if (begin >= end) return;
@@ -416,8 +420,8 @@ __global__ __launch_bounds__(kTravBlock) void k_shadow(Scene sc, ShadowQueue sq,
         };
     if (VOTE) {
         trace_range_vote<DEPTH, true, false>(sc, begin, end, stack + threadIdx.x, fetch, done, nn, nt);
-    } else if (begin + threadIdx.x < end) {  // wave_rays == 64
-        uint32_t i = begin + threadIdx.x;
+    } else if (begin + lane < end) {  // wave_rays == 64
+        uint32_t i = begin + lane;
         D3 o, d;
         double t_min, t_max;
         fetch(i, o, d, t_min, t_max);
@@ -674,7 +678,8 @@ __device__ __forceinline__ D3 diffuse_of(const Scene& sc, const Material& m, con
 
 // ------------------------------------------------------------------------------------------------
 // block-wide compaction: wave64 ballot + mbcnt prefix, one atomic per block
-__device__ __forceinline__ uint32_t compact_slot(bool alive, uint32_t* counter, uint32_t* lds /* kBlock/64 + 1 */) {
+template <int BLOCK = kBlock>
+__device__ __forceinline__ uint32_t compact_slot(bool alive, uint32_t* counter, uint32_t* lds /* BLOCK/64 + 1 */) {
     unsigned long long m = __ballot(alive);
     uint32_t lane_prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     uint32_t wave = threadIdx.x >> 6;
@@ -683,20 +688,30 @@ __device__ __forceinline__ uint32_t compact_slot(bool alive, uint32_t* counter, 
     if (threadIdx.x == 0) {
         uint32_t total = 0;
 #pragma unroll
-        for (int w = 0; w < kBlock / 64; ++w) {
+        for (int w = 0; w < BLOCK / 64; ++w) {
             uint32_t c = lds[w];
             lds[w] = total;
             total += c;
         }
-        lds[kBlock / 64] = total ? atomicAdd(counter, total) : 0u;
+        lds[BLOCK / 64] = total ? atomicAdd(counter, total) : 0u;
     }
     __syncthreads();
-    uint32_t pos = lds[kBlock / 64] + lds[wave] + lane_prefix;
+    uint32_t pos = lds[BLOCK / 64] + lds[wave] + lane_prefix;
     __syncthreads();
     return pos;
 }
 
-// shade: one lane per live path.
+// wave-wide compaction for one-wave workgroups: one atomic per wave
+__device__ __forceinline__ uint32_t compact_wave(bool alive, uint32_t* counter) {
+    unsigned long long m = __ballot(alive);
+    uint32_t lane_prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    uint32_t base = 0;
+    if ((threadIdx.x & 63) == 0 && m) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    return __shfl(base, 0) + lane_prefix;
+}
+
+// The shading of one path vertex (main.rs:292-315), shared by the shade kernel and the fused path
+// kernel.
 //   FIRST = bounce 0: queue index == slot, throughput == 1, and the camera ray is recomputed from
 //           the pixel (same arithmetic as the generate stage) instead of being read back from HBM.
 //   LAST  = bounce == max_bounces: only main.rs:299/307 remain (the reference still samples the
@@ -704,6 +719,145 @@ __device__ __forceinline__ uint32_t compact_slot(bool alive, uint32_t* counter, 
 //           even loaded unless NEE needs them for the MIS weight.
 //   PLAIN = the scene has only untextured Lambertian materials: the Glossy and texture code is
 //           compiled out, which is what keeps this kernel's register count (and occupancy) sane.
+//   FUSED = o, d hold the ray (the caller traced it); otherwise they are loaded here when needed.
+struct ShadeOut {
+    bool alive = false, shadow = false;  // the path continues / a shadow ray was made
+    uint32_t slot = 0;
+    D3 n_o, n_d, n_T;  // next ray and throughput
+    double n_pdf = 0.;
+    D3 s_d, s_c;  // shadow ray direction and the radiance it carries if unoccluded
+    double s_tmax = 0.;
+};
+template <bool FIRST, bool LAST, bool NEE, bool PLAIN, bool FUSED>
+__device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, uint32_t bounce, const Queue& in,
+                                             uint32_t i, uint32_t leaf, double t_hit, D3 o, D3 d, const Sample3& ls,
+                                             ShadeOut& r) {
+    const uint32_t slot = FIRST ? i : in.slot[i];
+    r.slot = slot;
+    uint32_t s = slot / fr.n_tile_pixels, p = slot - s * fr.n_tile_pixels;
+    uint32_t ty = p / fr.tile_w, tx = p - ty * fr.tile_w;
+    uint32_t pixel = (fr.y0 + ty) * fr.width + fr.x0 + tx;
+    uint64_t sample = fr.sample_base + s;
+    constexpr bool kNeedRay = !LAST || NEE;
+    if (!FUSED) {  // FUSED: the caller traced the ray in this kernel and still holds it
+        if (FIRST) {
+            PixelArgs a = pixel_args(fr.x0 + tx, fr.y0 + ty, fr.width, fr.height, fr.jitter[2 * s], fr.jitter[2 * s + 1]);
+            o = ld3(sc.cam.eye);
+            d = camera_dir(sc.cam, a.x, a.y);
+        } else if (kNeedRay) {
+            o = mk(in.o[0][i], in.o[1][i], in.o[2][i]);
+            d = mk(in.d[0][i], in.d[1][i], in.d[2][i]);
+        }
+    }
+    D3 T = FIRST ? mk(1., 1., 1.) : mk(in.T[0][i], in.T[1][i], in.T[2][i]);
+    D3 add;  // what main.rs:299 / :307 adds to color_result
+    if (leaf == PT_MISS) {
+        add = T * ld3(sc.background);  // main.rs:299
+    } else if (!kNeedRay) {
+        uint32_t mat = (uint32_t)__float_as_int(sc.tris[(size_t)leaf * 3 + 1].w);
+        const Material& m = sc.mats[mat];
+        D3 le = (!PLAIN && m.kind == PT_MAT_GLOSSY) ? mk(0., 0., 0.) : ld3(m.emission);  // microfacet.rs:33-35
+        add = T * le;  // main.rs:307
+    } else {
+        const double t = t_hit;
+        TriV tr;
+        uint32_t mat;
+        D3 position, normal;
+        hit_geometry(sc, leaf, o, d, t, tr, mat, position, normal);
+        const Material& m = sc.mats[mat];
+        D3 le = (!PLAIN && m.kind == PT_MAT_GLOSSY) ? mk(0., 0., 0.) : ld3(m.emission);  // microfacet.rs:33-35
+        add = T * le;  // main.rs:307
+        if (NEE && !FIRST && (le.x != 0. || le.y != 0. || le.z != 0.)) {
+            // MIS weight of a BRDF-sampled hit on a light (balance heuristic)
+            D3 ln = normalize(cross(tr.v1 - tr.v0, tr.v2 - tr.v0));
+            double cos_l = fabs(dot(ln, d));
+            double p_l = cos_l <= 0. ? 0. : t * t / (sc.light_area * cos_l);
+            double pp = in.prev_pdf[i];
+            double wgt = pp > 0. ? pp / (pp + p_l) : 0.;
+            add = T * le * wgt;
+        }
+        if (!LAST) {
+            D3 diffuse = mk(0., 0., 0.);
+            if (PLAIN) diffuse = ld3(m.color);
+            else if (m.kind != PT_MAT_GLOSSY) diffuse = diffuse_of(sc, m, tr, leaf, o, d, position, normal, fr, FIRST, pixel, s);
+            if (NEE && sc.n_lights) {
+                double r0, r1;
+                uniform2(fr.seed, pixel, sample, bounce, STREAM_LIGHT, r0, r1);
+                double target = r0 * sc.light_area;
+                uint32_t lo_i = 0, hi_i = sc.n_lights - 1;  // first light with cdf > target, else last
+                while (lo_i < hi_i) {
+                    uint32_t mid = (lo_i + hi_i) >> 1;
+                    if (sc.lights[mid].cdf <= target) lo_i = mid + 1; else hi_i = mid;
+                }
+                const Light& L = sc.lights[lo_i];
+                double cdf_lo = lo_i ? sc.lights[lo_i - 1].cdf : 0.;
+                double u1 = (target - cdf_lo) / (L.cdf - cdf_lo);
+                if (!(u1 >= 0.)) u1 = 0.;
+                if (u1 > 1.) u1 = 1.;
+                double su = sqrt(u1);
+                double b0 = 1. - su, b1 = r1 * su;
+                D3 lp = ld3(L.v0) * b0 + ld3(L.v1) * b1 + ld3(L.v2) * (1. - b0 - b1);
+                D3 diff = lp - position;
+                double dist = length(diff);
+                D3 wl = diff / dist;
+                D3 wo = -d;
+                double p_b;
+                if ((!PLAIN && m.kind == PT_MAT_GLOSSY)) {
+                    double pg = glossy_pdf_dir(m.width, wo, wl, normal);
+                    p_b = pg > 0. ? pg : 0.;
+                } else {
+                    double c = dot(normal, wl);
+                    p_b = c > 0. ? c * PT_FRAC_1_PI : 0.;
+                }
+                double cos_l = fabs(dot(ld3(L.normal), wl));
+                double p_l = cos_l <= 0. ? 0. : dist * dist / (sc.light_area * cos_l);
+                if (p_l > 0. && p_b > 0. && dist > 0.) {
+                    D3 f = (!PLAIN && m.kind == PT_MAT_GLOSSY) ? glossy_f(m.width, ld3(m.color), wo, wl, normal)
+                                                   : diffuse * PT_FRAC_1_PI;
+                    double cosn = fabs(dot(wl, normal));
+                    double wgt = p_l / (p_l + p_b);
+                    r.s_c = T * f * ld3(L.emission) * (cosn * wgt / p_l);
+                    r.s_d = wl;
+                    r.s_tmax = dist * (1. - 1e-9);
+                    r.shadow = true;
+                }
+            }
+            double xi1, xi2;
+            uniform2(fr.seed, pixel, sample, bounce, STREAM_BRDF, xi1, xi2);
+            Brdf bs = (!PLAIN && m.kind == PT_MAT_GLOSSY) ? glossy_sample(m.width, ld3(m.color), d, normal, xi1, xi2)
+                                              : lambertian_sample(diffuse, normal, xi1, xi2);
+            r.n_T = T * (bs.f * fabs(dot(bs.wi, normal)) / bs.pdf);  // main.rs:311
+            r.n_o = position;                                        // main.rs:314
+            r.n_d = bs.wi;
+            r.n_pdf = bs.pdf > 0. ? bs.pdf : 0.;
+            r.alive = true;
+        }
+    }
+    // color_result += add.  Adding +-0 never changes the sum (it starts at +0), NaN != 0 is true.
+    if (FIRST) {
+        ls.c[0][slot] = 0. + add.x; ls.c[1][slot] = 0. + add.y; ls.c[2][slot] = 0. + add.z;
+    } else if (add.x != 0. || add.y != 0. || add.z != 0.) {
+        ls.c[0][slot] += add.x; ls.c[1][slot] += add.y; ls.c[2][slot] += add.z;
+    }
+}
+
+template <bool NEE>
+__device__ __forceinline__ void push_path(const Queue& out, uint32_t pos, const ShadeOut& r) {
+    out.o[0][pos] = r.n_o.x; out.o[1][pos] = r.n_o.y; out.o[2][pos] = r.n_o.z;
+    out.d[0][pos] = r.n_d.x; out.d[1][pos] = r.n_d.y; out.d[2][pos] = r.n_d.z;
+    out.T[0][pos] = r.n_T.x; out.T[1][pos] = r.n_T.y; out.T[2][pos] = r.n_T.z;
+    out.slot[pos] = r.slot;
+    if (NEE) out.prev_pdf[pos] = r.n_pdf;
+}
+__device__ __forceinline__ void push_shadow(const ShadowQueue& sq, uint32_t spos, const ShadeOut& r) {
+    sq.o[0][spos] = r.n_o.x; sq.o[1][spos] = r.n_o.y; sq.o[2][spos] = r.n_o.z;
+    sq.d[0][spos] = r.s_d.x; sq.d[1][spos] = r.s_d.y; sq.d[2][spos] = r.s_d.z;
+    sq.tmax[spos] = r.s_tmax;
+    sq.c[0][spos] = r.s_c.x; sq.c[1][spos] = r.s_c.y; sq.c[2][spos] = r.s_c.z;
+    sq.slot[spos] = r.slot;
+}
+
+// shade: one lane per live path.
 template <bool FIRST, bool LAST, bool NEE, bool PLAIN>
 __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t bounce, Queue in, Hits hits,
                                                   Live live, Queue out, Push out_push, ShadowQueue sq, Push sq_push,
@@ -714,140 +868,79 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
     uint32_t n = live_end(live, blockIdx.x * kBlock);
     if (blockIdx.x * kBlock >= n) return;  // whole block idle
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    bool active = i < n;
     const uint32_t region = blockIdx.x % kSegs;  // the segment this workgroup appends to
-    bool alive = false, shadow = false;
-    uint32_t slot = 0;
-    D3 n_o = mk(0, 0, 0), n_d = n_o, n_T = n_o;
-    double n_pdf = 0.;
-    D3 s_d = n_o, s_c = n_o;
-    double s_tmax = 0.;
-    if (active) {
-        slot = FIRST ? i : in.slot[i];
-        uint32_t s = slot / fr.n_tile_pixels, p = slot - s * fr.n_tile_pixels;
-        uint32_t ty = p / fr.tile_w, tx = p - ty * fr.tile_w;
-        uint32_t pixel = (fr.y0 + ty) * fr.width + fr.x0 + tx;
-        uint64_t sample = fr.sample_base + s;
-        constexpr bool kNeedRay = !LAST || NEE;
-        D3 o = mk(0., 0., 0.), d = o;
+    ShadeOut r;
+    r.n_o = r.n_d = r.n_T = r.s_d = r.s_c = mk(0., 0., 0.);
+    if (i < n) {
+        uint32_t leaf = hits.tri[i];
+        // the hit distance is only needed (and only loaded) where the vertex is shaded in full
+        double t = (leaf != PT_MISS && (!LAST || NEE)) ? hits.t[i] : 0.;
+        shade_vertex<FIRST, LAST, NEE, PLAIN, false>(sc, fr, bounce, in, i, leaf, t, mk(0., 0., 0.), mk(0., 0., 0.), ls, r);
+    }
+    if (LAST) return;  // nothing continues
+    uint32_t pos = region * out_push.seg_size + compact_slot(r.alive, out_push.counts + region, lds_a);
+    if (r.alive) push_path<NEE>(out, pos, r);
+    if (NEE) {
+        uint32_t spos = region * sq_push.seg_size + compact_slot(r.shadow, sq_push.counts + region, lds_b);
+        if (r.shadow) push_shadow(sq, spos, r);
+    }
+}
+
+// path: extend and shade of one bounce in one kernel, one ray per lane (the while-while traversal).
+// The ray stays in registers between the two stages and the hit record never exists in memory: per
+// secondary ray 76 B are read and at most 76 B written, against 48 + 12 (extend) + 12 + 76 (shade)
+// + 76 for the two-kernel form, and the FP64-bound traversal of one wave overlaps the HBM-bound
+// shading of its neighbours on the same SIMD.  One wave per workgroup; survivors are appended with
+// one atomic per wave to segment blockIdx % kSegs.
+constexpr int kPathBlock = 128;  // measured on CornellBox 1080p: 64 -> 9.38, 128 -> 11.09, 256 -> 10.93, 512 -> 9.90 Gsamples/s
+template <int DEPTH, bool FIRST, bool LAST, bool NEE, bool PLAIN>
+__global__ __launch_bounds__(kPathBlock) void k_path(Scene sc, Frame fr, uint32_t bounce, Queue in, Live live, Queue out,
+                                                 Push out_push, ShadowQueue sq, Push sq_push, Sample3 ls,
+                                                 Counters* ctr) {
+    __shared__ int stack[DEPTH * kPathBlock];
+    __shared__ uint32_t lds_a[kPathBlock / 64 + 1];
+    __shared__ uint32_t lds_b[kPathBlock / 64 + 1];
+    if (ctr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->rays, live_total(live));
+    uint32_t begin, end;
+    if (live.counts) {
+        begin = blockIdx.x * kPathBlock;
+        if (begin >= live.n) return;
+        end = min(begin + kPathBlock, live_end(live, begin));
+    } else {
+        if (blockIdx.x >= trav_blocks(live.n, kPathBlock)) return;
+        begin = xcd_block(blockIdx.x, kChunkRays / kPathBlock) * kPathBlock;
+        end = min(begin + kPathBlock, live.n);
+    }
+    if (begin >= end) return;
+    const uint32_t i = begin + threadIdx.x;
+    ShadeOut r;
+    r.n_o = r.n_d = r.n_T = r.s_d = r.s_c = mk(0., 0., 0.);
+    if (i < end) {
+        D3 o, d;
         if (FIRST) {
+            uint32_t s = i / fr.n_tile_pixels, p = i - s * fr.n_tile_pixels;
+            uint32_t ty = p / fr.tile_w, tx = p - ty * fr.tile_w;
             PixelArgs a = pixel_args(fr.x0 + tx, fr.y0 + ty, fr.width, fr.height, fr.jitter[2 * s], fr.jitter[2 * s + 1]);
             o = ld3(sc.cam.eye);
             d = camera_dir(sc.cam, a.x, a.y);
-        } else if (kNeedRay) {
+        } else {
             o = mk(in.o[0][i], in.o[1][i], in.o[2][i]);
             d = mk(in.d[0][i], in.d[1][i], in.d[2][i]);
         }
-        D3 T = FIRST ? mk(1., 1., 1.) : mk(in.T[0][i], in.T[1][i], in.T[2][i]);
-        uint32_t leaf = hits.tri[i];
-        D3 add;  // what main.rs:299 / :307 adds to color_result
-        if (leaf == PT_MISS) {
-            add = T * ld3(sc.background);  // main.rs:299
-        } else if (!kNeedRay) {
-            uint32_t mat = (uint32_t)__float_as_int(sc.tris[(size_t)leaf * 3 + 1].w);
-            const Material& m = sc.mats[mat];
-            D3 le = (!PLAIN && m.kind == PT_MAT_GLOSSY) ? mk(0., 0., 0.) : ld3(m.emission);  // microfacet.rs:33-35
-            add = T * le;  // main.rs:307
-        } else {
-            double t = hits.t[i];
-            TriV tr;
-            uint32_t mat;
-            D3 position, normal;
-            hit_geometry(sc, leaf, o, d, t, tr, mat, position, normal);
-            const Material& m = sc.mats[mat];
-            D3 le = (!PLAIN && m.kind == PT_MAT_GLOSSY) ? mk(0., 0., 0.) : ld3(m.emission);  // microfacet.rs:33-35
-            add = T * le;  // main.rs:307
-            if (NEE && !FIRST && (le.x != 0. || le.y != 0. || le.z != 0.)) {
-                // MIS weight of a BRDF-sampled hit on a light (balance heuristic)
-                D3 ln = normalize(cross(tr.v1 - tr.v0, tr.v2 - tr.v0));
-                double cos_l = fabs(dot(ln, d));
-                double p_l = cos_l <= 0. ? 0. : t * t / (sc.light_area * cos_l);
-                double pp = in.prev_pdf[i];
-                double wgt = pp > 0. ? pp / (pp + p_l) : 0.;
-                add = T * le * wgt;
-            }
-            if (!LAST) {
-                D3 diffuse = mk(0., 0., 0.);
-                if (PLAIN) diffuse = ld3(m.color);
-                else if (m.kind != PT_MAT_GLOSSY) diffuse = diffuse_of(sc, m, tr, leaf, o, d, position, normal, fr, FIRST, pixel, s);
-                if (NEE && sc.n_lights) {
-                    double r0, r1;
-                    uniform2(fr.seed, pixel, sample, bounce, STREAM_LIGHT, r0, r1);
-                    double target = r0 * sc.light_area;
-                    uint32_t lo_i = 0, hi_i = sc.n_lights - 1;  // first light with cdf > target, else last
-                    while (lo_i < hi_i) {
-                        uint32_t mid = (lo_i + hi_i) >> 1;
-                        if (sc.lights[mid].cdf <= target) lo_i = mid + 1; else hi_i = mid;
-                    }
-                    const Light& L = sc.lights[lo_i];
-                    double cdf_lo = lo_i ? sc.lights[lo_i - 1].cdf : 0.;
-                    double u1 = (target - cdf_lo) / (L.cdf - cdf_lo);
-                    if (!(u1 >= 0.)) u1 = 0.;
-                    if (u1 > 1.) u1 = 1.;
-                    double su = sqrt(u1);
-                    double b0 = 1. - su, b1 = r1 * su;
-                    D3 lp = ld3(L.v0) * b0 + ld3(L.v1) * b1 + ld3(L.v2) * (1. - b0 - b1);
-                    D3 diff = lp - position;
-                    double dist = length(diff);
-                    D3 wl = diff / dist;
-                    D3 wo = -d;
-                    double p_b;
-                    if ((!PLAIN && m.kind == PT_MAT_GLOSSY)) {
-                        double pg = glossy_pdf_dir(m.width, wo, wl, normal);
-                        p_b = pg > 0. ? pg : 0.;
-                    } else {
-                        double c = dot(normal, wl);
-                        p_b = c > 0. ? c * PT_FRAC_1_PI : 0.;
-                    }
-                    double cos_l = fabs(dot(ld3(L.normal), wl));
-                    double p_l = cos_l <= 0. ? 0. : dist * dist / (sc.light_area * cos_l);
-                    if (p_l > 0. && p_b > 0. && dist > 0.) {
-                        D3 f = (!PLAIN && m.kind == PT_MAT_GLOSSY) ? glossy_f(m.width, ld3(m.color), wo, wl, normal)
-                                                       : diffuse * PT_FRAC_1_PI;
-                        double cosn = fabs(dot(wl, normal));
-                        double wgt = p_l / (p_l + p_b);
-                        s_c = T * f * ld3(L.emission) * (cosn * wgt / p_l);
-                        s_d = wl;
-                        s_tmax = dist * (1. - 1e-9);
-                        shadow = true;
-                    }
-                }
-                double xi1, xi2;
-                uniform2(fr.seed, pixel, sample, bounce, STREAM_BRDF, xi1, xi2);
-                Brdf bs = (!PLAIN && m.kind == PT_MAT_GLOSSY) ? glossy_sample(m.width, ld3(m.color), d, normal, xi1, xi2)
-                                                  : lambertian_sample(diffuse, normal, xi1, xi2);
-                n_T = T * (bs.f * fabs(dot(bs.wi, normal)) / bs.pdf);  // main.rs:311
-                n_o = position;                                        // main.rs:314
-                n_d = bs.wi;
-                n_pdf = bs.pdf > 0. ? bs.pdf : 0.;
-                alive = true;
-            }
-        }
-        // color_result += add.  Adding +-0 never changes the sum (it starts at +0), NaN != 0 is true.
-        if (FIRST) {
-            ls.c[0][slot] = 0. + add.x; ls.c[1][slot] = 0. + add.y; ls.c[2][slot] = 0. + add.z;
-        } else if (add.x != 0. || add.y != 0. || add.z != 0.) {
-            ls.c[0][slot] += add.x; ls.c[1][slot] += add.y; ls.c[2][slot] += add.z;
-        }
+        double t = 1.7976931348623157e308;  // ray.rs:22 f64::MAX; t_min = 1e-5 (ray.rs:21)
+        uint32_t nn = 0, nt = 0;
+        uint32_t leaf = traverse<DEPTH, false, false, kPathBlock>(sc, o, d, 1e-5, t, stack + threadIdx.x, nn, nt);
+        shade_vertex<FIRST, LAST, NEE, PLAIN, true>(sc, fr, bounce, in, i, leaf, t, o, d, ls, r);
     }
     if (LAST) return;  // nothing continues
-    uint32_t pos = region * out_push.seg_size + compact_slot(alive, out_push.counts + region, lds_a);
-    if (alive) {
-        out.o[0][pos] = n_o.x; out.o[1][pos] = n_o.y; out.o[2][pos] = n_o.z;
-        out.d[0][pos] = n_d.x; out.d[1][pos] = n_d.y; out.d[2][pos] = n_d.z;
-        out.T[0][pos] = n_T.x; out.T[1][pos] = n_T.y; out.T[2][pos] = n_T.z;
-        out.slot[pos] = slot;
-        if (NEE) out.prev_pdf[pos] = n_pdf;
-    }
+    const uint32_t region = blockIdx.x % kSegs;
+    uint32_t pos = region * out_push.seg_size + (kPathBlock == 64 ? compact_wave(r.alive, out_push.counts + region)
+                                                                   : compact_slot<kPathBlock>(r.alive, out_push.counts + region, lds_a));
+    if (r.alive) push_path<NEE>(out, pos, r);
     if (NEE) {
-        uint32_t spos = region * sq_push.seg_size + compact_slot(shadow, sq_push.counts + region, lds_b);
-        if (shadow) {
-            sq.o[0][spos] = n_o.x; sq.o[1][spos] = n_o.y; sq.o[2][spos] = n_o.z;
-            sq.d[0][spos] = s_d.x; sq.d[1][spos] = s_d.y; sq.d[2][spos] = s_d.z;
-            sq.tmax[spos] = s_tmax;
-            sq.c[0][spos] = s_c.x; sq.c[1][spos] = s_c.y; sq.c[2][spos] = s_c.z;
-            sq.slot[spos] = slot;
-        }
+        uint32_t spos = region * sq_push.seg_size + (kPathBlock == 64 ? compact_wave(r.shadow, sq_push.counts + region)
+                                                                      : compact_slot<kPathBlock>(r.shadow, sq_push.counts + region, lds_b));
+        if (r.shadow) push_shadow(sq, spos, r);
     }
 }
 
@@ -948,7 +1041,8 @@ void launch_generate_rays(const Scene& sc, const Frame& fr, double* rays_out, hi
 template <bool STATS, bool PRIMARY, bool VOTE>
 static void launch_extend_v(const Scene& sc, const Frame& fr, Queue q, const double* tmin, const double* tmax, Live live,
                             uint32_t wr, Hits hits, Counters* ctr, hipStream_t st) {
-    dim3 g(live.counts ? (live.n + wr - 1) / wr : trav_blocks(live.n, wr)), b(kTravBlock);
+    const uint32_t br = wr * (kTravBlock / 64);  // rays per workgroup
+    dim3 g(live.counts ? (live.n + br - 1) / br : trav_blocks(live.n, br)), b(kTravBlock);
     if (sc.bvh_depth <= 8) hipLaunchKernelGGL((k_extend<8, STATS, PRIMARY, VOTE>), g, b, 0, st, sc, fr, q, tmin, tmax, live, wr, hits, ctr);
     else if (sc.bvh_depth <= 16 || getenv("PT_HACK16")) hipLaunchKernelGGL((k_extend<16, STATS, PRIMARY, VOTE>), g, b, 0, st, sc, fr, q, tmin, tmax, live, wr, hits, ctr);
     else hipLaunchKernelGGL((k_extend<32, STATS, PRIMARY, VOTE>), g, b, 0, st, sc, fr, q, tmin, tmax, live, wr, hits, ctr);
@@ -998,9 +1092,49 @@ void launch_shade(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, H
     else if (last) launch_shade_t<false, true>(nee, g, b, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls);
     else launch_shade_t<false, false>(nee, g, b, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls);
 }
+template <int DEPTH, bool FIRST, bool LAST>
+static void launch_path_t(bool nee, dim3 g, dim3 b, hipStream_t st, const Scene& sc, const Frame& fr, uint32_t bounce,
+                          Queue in, Live live, Queue out, Push out_push, ShadowQueue sq, Push sq_push, Sample3 ls,
+                          Counters* ctr) {
+    if (sc.plain) {
+        if (nee) hipLaunchKernelGGL((k_path<DEPTH, FIRST, LAST, true, true>), g, b, 0, st, sc, fr, bounce, in, live, out, out_push, sq, sq_push, ls, ctr);
+        else hipLaunchKernelGGL((k_path<DEPTH, FIRST, LAST, false, true>), g, b, 0, st, sc, fr, bounce, in, live, out, out_push, sq, sq_push, ls, ctr);
+    } else {
+        if (nee) hipLaunchKernelGGL((k_path<DEPTH, FIRST, LAST, true, false>), g, b, 0, st, sc, fr, bounce, in, live, out, out_push, sq, sq_push, ls, ctr);
+        else hipLaunchKernelGGL((k_path<DEPTH, FIRST, LAST, false, false>), g, b, 0, st, sc, fr, bounce, in, live, out, out_push, sq, sq_push, ls, ctr);
+    }
+}
+// The fused form exists where a bounce is traced one ray per lane: every bounce of a shallow tree
+// (the 8-entry stack instantiation) and the primary bounce of any tree.
+bool path_fusable(const Scene& sc, uint32_t bounce) {
+    if (!sc.fuse) return false;
+    return bounce == 0 ? !sc.vote_primary : (sc.bvh_depth <= 8 && !sc.vote_secondary);
+}
+bool launch_path(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, Live live, Queue out, Push out_push,
+                 ShadowQueue sq, Push sq_push, Sample3 ls, Counters* ctr, hipStream_t st) {
+    if (!path_fusable(sc, bounce)) return false;
+    if (!live.n) return true;
+    bool nee = (fr.flags & PT_FLAG_NEE) != 0 && sc.n_lights > 0;
+    bool first = bounce == 0, last = bounce >= fr.max_bounces;
+    dim3 g(live.counts ? (live.n + kPathBlock - 1) / kPathBlock : trav_blocks(live.n, kPathBlock)), b(kPathBlock);
+    #define PT_PATH(D, F, L) launch_path_t<D, F, L>(nee, g, b, st, sc, fr, bounce, in, live, out, out_push, sq, sq_push, ls, ctr)
+    if (sc.bvh_depth <= 8) {
+        if (first && last) PT_PATH(8, true, true);
+        else if (first) PT_PATH(8, true, false);
+        else if (last) PT_PATH(8, false, true);
+        else PT_PATH(8, false, false);
+    } else if (sc.bvh_depth <= 16) {  // deeper trees: primary bounce only (path_fusable)
+        if (last) PT_PATH(16, true, true); else PT_PATH(16, true, false);
+    } else {
+        if (last) PT_PATH(32, true, true); else PT_PATH(32, true, false);
+    }
+    #undef PT_PATH
+    return true;
+}
 template <bool VOTE>
 static void launch_shadow_v(const Scene& sc, ShadowQueue sq, Live live, uint32_t wr, Sample3 ls, Counters* ctr, hipStream_t st) {
-    dim3 g((live.n + wr - 1) / wr), b(kTravBlock);
+    const uint32_t br = wr * (kTravBlock / 64);
+    dim3 g((live.n + br - 1) / br), b(kTravBlock);
     if (sc.bvh_depth <= 8) hipLaunchKernelGGL((k_shadow<8, VOTE>), g, b, 0, st, sc, sq, live, wr, ls, ctr);
     else if (sc.bvh_depth <= 16) hipLaunchKernelGGL((k_shadow<16, VOTE>), g, b, 0, st, sc, sq, live, wr, ls, ctr);
     else hipLaunchKernelGGL((k_shadow<32, VOTE>), g, b, 0, st, sc, sq, live, wr, ls, ctr);

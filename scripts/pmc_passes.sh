@@ -17,23 +17,4 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
   echo "pass $i ($grp) rc=$rc"
   if [ $rc -ne 0 ]; then tail -3 $OUT/p$i.log; fi
 done
-python3 - "$OUT" <<'PY'
-import csv, glob, sys, collections
-out = sys.argv[1]
-agg = collections.defaultdict(lambda: collections.defaultdict(float))
-cnt = collections.defaultdict(int)
-for f in glob.glob(out + '/p*/**/*counter_collection.csv', recursive=True):
-    for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name'].split('(')[0][-40:]
-        agg[k][r['Counter_Name']] += float(r['Counter_Value'])
-        if r['Counter_Name'] in ('SQ_WAVES', 'TCC_HIT_sum', 'FETCH_SIZE', 'WRITE_SIZE', 'SQ_INSTS_LDS', 'TA_BUSY_avr'):
-            cnt[(k, r['Counter_Name'])] += 1
-with open(out + '/summary.txt', 'w') as fo:
-    for k, d in agg.items():
-        if 'ptd' not in k: continue
-        fo.write(k + '\n')
-        for c, v in sorted(d.items()):
-            n = max(cnt.get((k, c), 0), 1)
-            fo.write(f'   {c:32s} total {v:.6g}\n')
-print(open(out + '/summary.txt').read())
-PY
+python3 $ROOT/scripts/pmc_aggregate.py "$OUT"

@@ -14,6 +14,8 @@ ls $OUT
 cd $ROOT
 bash scripts/pmc_passes.sh ${TAG}_cornell --steps 2 --warmup 0 --cpu-seconds 0 > $OUT/pmc_cornell.log 2>&1 || exit 1
 bash scripts/pmc_passes.sh ${TAG}_hf --scene heightfield --width 3840 --height 2160 --spp 2 --steps 1 --warmup 0 --cpu-seconds 0 > $OUT/pmc_hf.log 2>&1 || exit 1
+python3 scripts/pmc_traffic.py CornellBox_1920x1080_spp8_b2 gpurun_out/pmc_${TAG}_cornell $OUT/traffic.json > /dev/null
+python3 scripts/pmc_traffic.py heightfield_3840x2160_spp2_b2 gpurun_out/pmc_${TAG}_hf $OUT/traffic.json > /dev/null
 python3 scripts/pmc_summary.py gpurun_out/pmc_${TAG}_cornell/summary.txt > $OUT/pmc_cornell_digest.txt
 python3 scripts/pmc_summary.py gpurun_out/pmc_${TAG}_hf/summary.txt > $OUT/pmc_hf_digest.txt
 cat $OUT/pmc_cornell_digest.txt $OUT/pmc_hf_digest.txt

@@ -280,3 +280,25 @@ def test_two_lane_pipeline_is_bitwise_invariant(gpu, monkeypatch, nee):
     ref = oracle.render(cfg1, threads=16)
     img = two.render(cfg1)
     assert (np.abs(img - ref) > 1e-9 * np.maximum(1.0, np.abs(ref))).mean() < 1e-3
+
+
+@pytest.mark.parametrize("name", ["CornellBox", "Test", "glossy_planes", "heightfield40"])
+def test_fused_path_kernel_is_bitwise_identical(gpu, monkeypatch, name):
+    # extend+shade in one kernel (every bounce of a shallow tree, the primary bounce of a deep one)
+    # against the two-kernel form: same arithmetic per path, so the same image bit for bit; with
+    # textures and NEE as well
+    if name == "heightfield40":
+        from pathtracer_amd.synthetic import heightfield_box
+        data = heightfield_box(cells=40)
+    else:
+        data = pt.scene_data(name, textures=True) if name == "Test" else pt.scene_data(name)
+    monkeypatch.setenv("PT_FUSE", "0")
+    plain = pt.Scene(data, gpu)
+    monkeypatch.setenv("PT_FUSE", "1")
+    fused = pt.Scene(data, gpu)
+    monkeypatch.delenv("PT_FUSE")
+    for nee in (False, True):
+        for bounces in (0, 1, 3):
+            cfg = pt.Config(width=83, height=47, samples_pr_pixel=3, bounces=bounces, seed=12, nee=nee, drop_nonfinite=True)
+            a, b = plain.render(cfg), fused.render(cfg)
+            assert a.tobytes() == b.tobytes(), (name, nee, bounces)

@@ -180,4 +180,13 @@ def test_stats_counters(trio):
     assert st["nodes_visited"] >= 2 * st["rays"] and st["tris_tested"] > st["rays"] // 2
     k = st["kernel"]
     assert k["extend"]["launches"] == 3 and k["shade"]["launches"] == 3 and k["generate"]["launches"] == 0  # fused into bounce-0 extend/shade
-    assert k["extend"]["ms"] > 0
+    assert k["extend"]["ms"] > 0 and k["path"]["launches"] == 0   # level 2 counts in the extend kernel: unfused
+    # level 1 (timers only) runs the fused extend+shade kernel on this shallow tree
+    scene.reset_stats()
+    scene.set_profiling(1)
+    scene.render(cfg)
+    st1 = scene.stats()
+    scene.set_profiling(0)
+    k = st1["kernel"]
+    assert k["path"]["launches"] == 3 and k["extend"]["launches"] == 0 and k["shade"]["launches"] == 0
+    assert st1["rays"] == st["rays"]
