@@ -206,6 +206,24 @@ int pt_resolve_rgb8(const double* accum_rgb, size_t n_pixels, uint64_t iteration
 /* ---- mipmap.rs:25-42 Image::save_ppm: ASCII P3, one pixel per line. */
 int pt_write_ppm(const char* path, uint32_t width, uint32_t height, const uint8_t* rgb8);
 
+/* ---- checkpoint / resume of a progressive render.  The reference keeps its
+ * running sum `pixels` and the frame counter `iterations` only in memory (main.rs:396-400,434-436);
+ * a 4096-frame run that dies starts over.  A checkpoint is that pair on disk: the f64 sums, the
+ * number of frames they hold (= the sample_begin to resume from) and the seed they were drawn
+ * with; because the RNG is keyed by (seed, frame), resuming continues the very same sequence and
+ * the final image is bit-identical to an uninterrupted run.  File: 48-byte header (magic
+ * "PTACCUM1", width, height, frames, seed, FNV-1a-64 of the payload) + width*height*3 doubles,
+ * little endian.  pt_checkpoint_save writes to `path`.tmp and renames, so a crash mid-write leaves
+ * the previous checkpoint intact.  pt_checkpoint_load: accum_rgb NULL = header only; otherwise it
+ * must hold cap_pixels >= width*height pixels; a size, magic or checksum mismatch is PT_ERR_IO. */
+typedef struct pt_checkpoint_info {
+    uint32_t width, height;
+    uint64_t frames; /* frames accumulated so far */
+    uint64_t seed;
+} pt_checkpoint_info;
+int pt_checkpoint_save(const char* path, const pt_checkpoint_info* info, const double* accum_rgb);
+int pt_checkpoint_load(const char* path, pt_checkpoint_info* info, double* accum_rgb, size_t cap_pixels);
+
 /* profiling: level 0 = off, 1 = HIP-event time per kernel launch, 2 = also count BVH nodes
  * visited / triangles tested (instrumented extend kernel; slower). */
 int pt_set_profiling(pt_scene* scene, int level);

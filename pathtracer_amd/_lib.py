@@ -64,6 +64,10 @@ class pt_render_params(C.Structure):
                 ("seed", C.c_uint64)]
 
 
+class pt_checkpoint_info(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("frames", C.c_uint64), ("seed", C.c_uint64)]
+
+
 class pt_kernel_stat(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("ms", C.c_double)]
 
@@ -94,6 +98,8 @@ PROTOTYPES = {
     "pt_render_device": (C.c_int, [_vp, _P(pt_render_params), _vp, _vp]),
     "pt_resolve_rgb8": (C.c_int, [_P(C.c_double), C.c_size_t, C.c_uint64, _P(C.c_uint8)]),
     "pt_write_ppm": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, _P(C.c_uint8)]),
+    "pt_checkpoint_save": (C.c_int, [C.c_char_p, _P(pt_checkpoint_info), _P(C.c_double)]),
+    "pt_checkpoint_load": (C.c_int, [C.c_char_p, _P(pt_checkpoint_info), _P(C.c_double), C.c_size_t]),
     "pt_set_profiling": (C.c_int, [_vp, C.c_int]),
     "pt_get_stats": (C.c_int, [_vp, _P(pt_stats)]),
     "pt_reset_stats": (C.c_int, [_vp]),

@@ -13,8 +13,12 @@
 #include "pt_host.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <cstdio>
 #include <thread>
 
 namespace pth {
@@ -53,11 +57,35 @@ struct TNode {  // temporary tree
 constexpr int kBins = 16;
 constexpr int kMaxDepth = 30;  // inner-node levels; stack needs <= depth entries (< ptd::kStackDepth = 32)
 
+// fork-join over [0, n) in `threads` contiguous chunks (chunk t on thread t; the caller runs chunk 0)
+template <class F>
+void parallel_chunks(size_t n, uint32_t threads, F fn) {
+    threads = (uint32_t)std::max<size_t>(1, std::min<size_t>(threads, n / 4096 + 1));
+    auto bounds = [&](uint32_t t) { return n * t / threads; };
+    std::vector<std::thread> pool;
+    for (uint32_t t = 1; t < threads; ++t) pool.emplace_back([&, t] { fn(bounds(t), bounds(t + 1), t); });
+    fn(bounds(0), bounds(1), 0u);
+    for (auto& t : pool) t.join();
+}
+
+struct Pending {  // a subtree the top-level pass left for a worker thread
+    int node;
+    uint32_t first, count;
+    int depth;
+};
+
 struct Builder {
     std::vector<Ref>& refs;
     uint32_t max_leaf;
     std::vector<TNode> nodes;
     uint32_t max_depth = 0;
+    // top-level pass of a parallel build: ranges of at most `cut` references are not split but
+    // recorded in `pending` (their node holds only first/count until the subtree is spliced in)
+    uint32_t cut = 0;
+    std::vector<Pending>* pending = nullptr;
+    uint32_t threads = 1;            // the top-level pass also splits its big ranges with this many threads
+    std::vector<Ref>* scratch = nullptr;  // n references, for the out-of-place parallel partition
+    static constexpr uint32_t kParallelRange = 1u << 17;
 
     Builder(std::vector<Ref>& r, uint32_t ml) : refs(r), max_leaf(ml) {}
 
@@ -70,18 +98,43 @@ struct Builder {
     int build(uint32_t first, uint32_t count, int depth) {
         int idx = (int)nodes.size();
         nodes.emplace_back();
+        if (pending && count <= cut && count > max_leaf) {
+            nodes[idx].first = first;
+            nodes[idx].count = count;
+            pending->push_back({idx, first, count, depth});
+            return idx;
+        }
+        const uint32_t par = (threads > 1 && count >= kParallelRange) ? threads : 1;
         Box box, cbox;
         box.reset();
         cbox.reset();
-        for (uint32_t i = first; i < first + count; ++i) {
-            box.grow(refs[i].lo, refs[i].hi);
-            cbox.grow_pt(refs[i].c);
+        {
+            std::vector<Box> pb(par), pc(par);
+            parallel_chunks(count, par, [&](size_t b0, size_t b1, uint32_t t) {
+                Box bx, cx;
+                bx.reset();
+                cx.reset();
+                for (size_t i = first + b0; i < first + b1; ++i) {
+                    bx.grow(refs[i].lo, refs[i].hi);
+                    cx.grow_pt(refs[i].c);
+                }
+                pb[t] = bx;
+                pc[t] = cx;
+            });
+            for (uint32_t t = 0; t < par; ++t) {  // unused chunks keep the reset (empty) box
+                if (pb[t].lo[0] <= pb[t].hi[0]) { box.grow(pb[t].lo, pb[t].hi); cbox.grow(pc[t].lo, pc[t].hi); }
+            }
         }
         nodes[idx].box = box;
         nodes[idx].first = first;
         nodes[idx].count = count;
         max_depth = std::max(max_depth, (uint32_t)depth);
-        if (count <= max_leaf) return idx;
+        if (count <= max_leaf) {
+            // canonical leaf: triangles by id, so the output does not depend on how the ranges
+            // above were permuted (serial std::partition vs. the stable parallel one)
+            std::sort(refs.begin() + first, refs.begin() + first + count, [](const Ref& a, const Ref& b) { return a.id < b.id; });
+            return idx;
+        }
 
         uint32_t mid = 0;
         bool have_split = false;
@@ -98,10 +151,27 @@ struct Builder {
                 Box bb[kBins];
                 uint32_t bc[kBins];
                 for (int b = 0; b < kBins; ++b) { bb[b].reset(); bc[b] = 0; }
-                for (uint32_t i = first; i < first + count; ++i) {
-                    int b = std::min(kBins - 1, (int)((refs[i].c[axis] - cmin) * scale));
-                    bb[b].grow(refs[i].lo, refs[i].hi);
-                    bc[b]++;
+                if (par == 1) {
+                    for (uint32_t i = first; i < first + count; ++i) {
+                        int b = std::min(kBins - 1, (int)((refs[i].c[axis] - cmin) * scale));
+                        bb[b].grow(refs[i].lo, refs[i].hi);
+                        bc[b]++;
+                    }
+                } else {  // per-thread bins, merged: min/max and integer counts are order-independent
+                    struct Bins { Box bb[kBins]; uint32_t bc[kBins]; };
+                    std::vector<Bins> pbins(par);
+                    for (auto& pbn : pbins) for (int b = 0; b < kBins; ++b) { pbn.bb[b].reset(); pbn.bc[b] = 0; }
+                    parallel_chunks(count, par, [&](size_t b0, size_t b1, uint32_t t) {
+                        Bins& my = pbins[t];
+                        for (size_t i = first + b0; i < first + b1; ++i) {
+                            int b = std::min(kBins - 1, (int)((refs[i].c[axis] - cmin) * scale));
+                            my.bb[b].grow(refs[i].lo, refs[i].hi);
+                            my.bc[b]++;
+                        }
+                    });
+                    for (auto& pbn : pbins)
+                        for (int b = 0; b < kBins; ++b)
+                            if (pbn.bc[b]) { bb[b].grow(pbn.bb[b].lo, pbn.bb[b].hi); bc[b] += pbn.bc[b]; }
                 }
                 float right_area[kBins];
                 uint32_t right_cnt[kBins];
@@ -127,11 +197,34 @@ struct Builder {
             if (best_axis >= 0) {
                 float cmin = cbox.lo[best_axis], cmax = cbox.hi[best_axis];
                 float scale = (float)kBins / (cmax - cmin);
-                auto it = std::partition(refs.begin() + first, refs.begin() + first + count, [&](const Ref& r) {
+                auto is_left = [&](const Ref& r) {
                     int b = std::min(kBins - 1, (int)((r.c[best_axis] - cmin) * scale));
                     return b <= best_bin;
-                });
-                mid = (uint32_t)(it - refs.begin());
+                };
+                if (par == 1 || !scratch) {
+                    auto it = std::partition(refs.begin() + first, refs.begin() + first + count, is_left);
+                    mid = (uint32_t)(it - refs.begin());
+                } else {  // stable out-of-place partition: count per chunk, prefix, scatter, copy back
+                    std::vector<size_t> nl(par + 1, 0);
+                    parallel_chunks(count, par, [&](size_t b0, size_t b1, uint32_t t) {
+                        size_t c = 0;
+                        for (size_t i = first + b0; i < first + b1; ++i) c += is_left(refs[i]);
+                        nl[t + 1] = c;
+                    });
+                    for (uint32_t t = 0; t < par; ++t) nl[t + 1] += nl[t];
+                    const size_t n_left = nl[par];
+                    Ref* tmp = scratch->data() + first;
+                    parallel_chunks(count, par, [&](size_t b0, size_t b1, uint32_t t) {
+                        size_t l = nl[t], r = n_left + (b0 - nl[t]);
+                        for (size_t i = first + b0; i < first + b1; ++i) {
+                            if (is_left(refs[i])) tmp[l++] = refs[i]; else tmp[r++] = refs[i];
+                        }
+                    });
+                    parallel_chunks(count, par, [&](size_t b0, size_t b1, uint32_t) {
+                        std::memcpy(&refs[first + b0], tmp + b0, (b1 - b0) * sizeof(Ref));
+                    });
+                    mid = first + (uint32_t)n_left;
+                }
                 have_split = mid > first && mid < first + count;
             }
         }
@@ -172,29 +265,94 @@ int bvh_build(const float* verts, uint32_t n_verts, const uint32_t* tris, uint32
     out_order.clear();
     out_depth = 0;
     if (n_tris == 0) return PT_OK;
+    auto T0 = std::chrono::steady_clock::now(); auto lap=[&](const char* w){ if(getenv("PT_BVH_TIMING")){auto t=std::chrono::steady_clock::now(); fprintf(stderr,"bvh %s %.3f s\n",w,std::chrono::duration<double>(t-T0).count()); T0=t;} };
     std::vector<Ref> refs(n_tris);
+    uint32_t n_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* e = getenv("PT_BVH_THREADS")) n_threads = (uint32_t)std::max(1, std::min(64, atoi(e)));
+    if (n_tris < (1u << 16)) n_threads = 1;
     double max_abs = 0.;
-    for (uint32_t i = 0; i < n_tris; ++i) {
-        Ref& r = refs[i];
-        for (int a = 0; a < 3; ++a) { r.lo[a] = INFINITY; r.hi[a] = -INFINITY; }
-        for (int k = 0; k < 3; ++k) {
-            uint32_t v = tris[3 * i + k];
-            if (v >= n_verts) return PT_ERR_INVALID;
-            for (int a = 0; a < 3; ++a) {
-                float x = verts[3 * v + a];
-                if (!std::isfinite(x)) return PT_ERR_INVALID;
-                r.lo[a] = std::min(r.lo[a], x);
-                r.hi[a] = std::max(r.hi[a], x);
-                max_abs = std::max(max_abs, (double)std::fabs(x));
+    {
+        std::vector<double> pmax(n_threads, 0.);
+        std::vector<int> bad(n_threads, 0);
+        parallel_chunks(n_tris, n_threads, [&](size_t b0, size_t b1, uint32_t t) {
+            double m = 0.;
+            for (size_t i = b0; i < b1; ++i) {
+                Ref& r = refs[i];
+                for (int a = 0; a < 3; ++a) { r.lo[a] = INFINITY; r.hi[a] = -INFINITY; }
+                for (int k = 0; k < 3; ++k) {
+                    uint32_t v = tris[3 * i + k];
+                    if (v >= n_verts) { bad[t] = 1; return; }
+                    for (int a = 0; a < 3; ++a) {
+                        float x = verts[3 * (size_t)v + a];
+                        if (!std::isfinite(x)) { bad[t] = 1; return; }
+                        r.lo[a] = std::min(r.lo[a], x);
+                        r.hi[a] = std::max(r.hi[a], x);
+                        m = std::max(m, (double)std::fabs(x));
+                    }
+                }
+                for (int a = 0; a < 3; ++a) r.c[a] = 0.5f * r.lo[a] + 0.5f * r.hi[a];
+                r.id = (uint32_t)i;
             }
+            pmax[t] = m;
+        });
+        for (uint32_t t = 0; t < n_threads; ++t) {
+            if (bad[t]) return PT_ERR_INVALID;
+            max_abs = std::max(max_abs, pmax[t]);
         }
-        for (int a = 0; a < 3; ++a) r.c[a] = 0.5f * r.lo[a] + 0.5f * r.hi[a];
-        r.id = i;
     }
+    lap("refs");
     Builder b(refs, max_leaf);
-    b.nodes.reserve((size_t)n_tris * 2 / max_leaf + 16);
-    b.build(0, n_tris, 0);
+    if (n_threads > 1) {
+        std::vector<Pending> pending;
+        std::vector<Ref> scratch(n_tris);
+        b.threads = n_threads;
+        b.scratch = &scratch;
+        b.cut = std::max(n_tris / (8 * n_threads), 4096u);
+        b.pending = &pending;
+        b.build(0, n_tris, 0);
+        lap("top");
+        std::vector<Builder> subs;
+        subs.reserve(pending.size());
+        for (size_t i = 0; i < pending.size(); ++i) subs.emplace_back(refs, max_leaf);
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (size_t i; (i = next.fetch_add(1)) < pending.size();) {
+                subs[i].nodes.reserve((size_t)pending[i].count * 2 / max_leaf + 16);
+                subs[i].build(pending[i].first, pending[i].count, pending[i].depth);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (uint32_t t = 1; t < n_threads; ++t) pool.emplace_back(work);
+        work();
+        for (auto& t : pool) t.join();
+        lap("subtrees");
+        std::vector<size_t> off(pending.size() + 1, b.nodes.size());
+        for (size_t i = 0; i < pending.size(); ++i) off[i + 1] = off[i] + subs[i].nodes.size();
+        b.nodes.resize(off[pending.size()]);
+        next = 0;
+        auto splice = [&]() {
+            for (size_t i; (i = next.fetch_add(1)) < pending.size();) {
+                const int o = (int)off[i];
+                for (size_t k = 0; k < subs[i].nodes.size(); ++k) {
+                    TNode n = subs[i].nodes[k];
+                    if (n.left >= 0) { n.left += o; n.right += o; }
+                    b.nodes[off[i] + k] = n;
+                }
+                b.nodes[pending[i].node] = b.nodes[off[i]];  // the subtree's root takes the placeholder's place
+                std::vector<TNode>().swap(subs[i].nodes);
+            }
+        };
+        pool.clear();
+        for (uint32_t t = 1; t < n_threads; ++t) pool.emplace_back(splice);
+        splice();
+        for (auto& t : pool) t.join();
+        for (size_t i = 0; i < pending.size(); ++i) b.max_depth = std::max(b.max_depth, subs[i].max_depth);
+    } else {
+        b.nodes.reserve((size_t)n_tris * 2 / max_leaf + 16);
+        b.build(0, n_tris, 0);
+    }
 
+    lap("splice");
     out_order.resize(n_tris);
     for (uint32_t i = 0; i < n_tris; ++i) out_order[i] = refs[i].id;
 
@@ -206,11 +364,20 @@ int bvh_build(const float* verts, uint32_t n_verts, const uint32_t* tris, uint32
             dst.bounds[child * 6 + 3 + a] = round_up((double)bx.hi[a] + pad);
         }
     };
-    // flatten: inner temp nodes get consecutive output indices in depth-first order
+    // flatten: inner temp nodes get consecutive output indices in depth-first (pre-)order
     std::vector<int> out_index(b.nodes.size(), -1);
     uint32_t n_inner = 0;
-    for (size_t i = 0; i < b.nodes.size(); ++i)
-        if (b.nodes[i].left >= 0) out_index[i] = (int)n_inner++;
+    {
+        std::vector<int> dfs{0};
+        while (!dfs.empty()) {
+            int i = dfs.back();
+            dfs.pop_back();
+            if (b.nodes[i].left < 0) continue;
+            out_index[i] = (int)n_inner++;
+            dfs.push_back(b.nodes[i].right);
+            dfs.push_back(b.nodes[i].left);
+        }
+    }
     if (n_inner == 0) {  // the root is a leaf: one node with a single child
         pt_bvh_node node;
         std::memset(&node, 0, sizeof node);
@@ -225,7 +392,7 @@ int bvh_build(const float* verts, uint32_t n_verts, const uint32_t* tris, uint32
     out_nodes.resize(n_inner);
     for (size_t i = 0; i < b.nodes.size(); ++i) {
         const TNode& n = b.nodes[i];
-        if (n.left < 0) continue;
+        if (n.left < 0 || out_index[i] < 0) continue;  // leaf, or the unused copy of a spliced subtree root
         pt_bvh_node node;
         std::memset(&node, 0, sizeof node);
         const TNode& l = b.nodes[n.left];
@@ -236,6 +403,7 @@ int bvh_build(const float* verts, uint32_t n_verts, const uint32_t* tris, uint32
         node.child[1] = r.left >= 0 ? out_index[n.right] : leaf_code(r);
         out_nodes[out_index[i]] = node;
     }
+    lap("flatten");
     out_depth = b.max_depth;
     return PT_OK;
 }

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <string>
 #include <cstdlib>
 #include <cstring>
 
@@ -200,6 +201,73 @@ int pt_write_ppm(const char* path, uint32_t width, uint32_t height, const uint8_
         std::fprintf(f, "%u %u %u\n", rgb8[3 * i], rgb8[3 * i + 1], rgb8[3 * i + 2]);
     if (std::fclose(f) != 0) { pth::set_error("write to %s failed", path); return PT_ERR_IO; }
     return PT_OK;
+}
+
+namespace {
+struct CkptHeader {
+    char magic[8];
+    uint32_t width, height;
+    uint64_t frames, seed, fnv;
+    uint64_t reserved;
+};
+static_assert(sizeof(CkptHeader) == 48, "checkpoint header layout");
+const char kCkptMagic[8] = {'P', 'T', 'A', 'C', 'C', 'U', 'M', '1'};
+uint64_t fnv1a64(const void* data, size_t n) {
+    const unsigned char* p = (const unsigned char*)data;
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+}  // namespace
+
+int pt_checkpoint_save(const char* path, const pt_checkpoint_info* info, const double* accum_rgb) {
+    if (!path || !info || !accum_rgb) { pth::set_error("null argument"); return PT_ERR_INVALID; }
+    if (info->width == 0 || info->height == 0) { pth::set_error("empty image"); return PT_ERR_INVALID; }
+    const size_t bytes = (size_t)info->width * info->height * 3 * sizeof(double);
+    CkptHeader h{};
+    std::memcpy(h.magic, kCkptMagic, 8);
+    h.width = info->width; h.height = info->height; h.frames = info->frames; h.seed = info->seed;
+    h.fnv = fnv1a64(accum_rgb, bytes);
+    std::string tmp = std::string(path) + ".tmp";
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) { pth::set_error("cannot create %s", tmp.c_str()); return PT_ERR_IO; }
+    bool ok = std::fwrite(&h, sizeof h, 1, f) == 1 && std::fwrite(accum_rgb, 1, bytes, f) == bytes;
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok || std::rename(tmp.c_str(), path) != 0) {
+        std::remove(tmp.c_str());
+        pth::set_error("write to %s failed", path);
+        return PT_ERR_IO;
+    }
+    return PT_OK;
+}
+
+int pt_checkpoint_load(const char* path, pt_checkpoint_info* info, double* accum_rgb, size_t cap_pixels) {
+    if (!path || !info) { pth::set_error("null argument"); return PT_ERR_INVALID; }
+    FILE* f = std::fopen(path, "rb");
+    if (!f) { pth::set_error("cannot open %s", path); return PT_ERR_IO; }
+    CkptHeader h{};
+    int rc = PT_OK;
+    if (std::fread(&h, sizeof h, 1, f) != 1 || std::memcmp(h.magic, kCkptMagic, 8) != 0 || h.width == 0 || h.height == 0) {
+        pth::set_error("%s is not a checkpoint", path);
+        rc = PT_ERR_IO;
+    } else {
+        info->width = h.width; info->height = h.height; info->frames = h.frames; info->seed = h.seed;
+        const size_t px = (size_t)h.width * h.height, bytes = px * 3 * sizeof(double);
+        if (accum_rgb) {
+            if (cap_pixels < px) {
+                pth::set_error("checkpoint is %ux%u, buffer holds %zu pixels", h.width, h.height, cap_pixels);
+                rc = PT_ERR_INVALID;
+            } else if (std::fread(accum_rgb, 1, bytes, f) != bytes || std::fgetc(f) != EOF) {
+                pth::set_error("%s: truncated or oversized payload", path);
+                rc = PT_ERR_IO;
+            } else if (fnv1a64(accum_rgb, bytes) != h.fnv) {
+                pth::set_error("%s: checksum mismatch", path);
+                rc = PT_ERR_IO;
+            }
+        }
+    }
+    std::fclose(f);
+    return rc;
 }
 
 const char* pt_last_error(void) { return pth::last_error(); }

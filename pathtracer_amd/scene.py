@@ -353,6 +353,42 @@ def save_ppm(path: str, rgb8: np.ndarray) -> None:
     L.check(L.lib.pt_write_ppm(os.fsencode(path), w, h, _ptr(rgb8, C.c_uint8)))
 
 
+def save_checkpoint(path: str, accum: np.ndarray, frames: int, seed: int) -> None:
+    """the running f64 sums plus how many frames they hold (pt_checkpoint_save)."""
+    accum = np.ascontiguousarray(accum, dtype=np.float64)
+    info = L.pt_checkpoint_info(accum.shape[1], accum.shape[0], frames, seed)
+    L.check(L.lib.pt_checkpoint_save(os.fsencode(path), C.byref(info), _ptr(accum, C.c_double)))
+
+
+def load_checkpoint(path: str):
+    """-> (accum[h, w, 3] f64, frames, seed); raises PtError on a damaged file."""
+    info = L.pt_checkpoint_info()
+    L.check(L.lib.pt_checkpoint_load(os.fsencode(path), C.byref(info), None, 0))
+    accum = np.empty((info.height, info.width, 3), np.float64)
+    L.check(L.lib.pt_checkpoint_load(os.fsencode(path), C.byref(info), _ptr(accum, C.c_double),
+                                     info.width * info.height))
+    return accum, int(info.frames), int(info.seed)
+
+
+def render_progressive(scene: "Scene", cfg: "Config", path: str, every: int = 64) -> np.ndarray:
+    """Renders cfg.samples_pr_pixel frames, checkpointing to `path` every `every` frames and
+    resuming from `path` if it exists (same size and seed required).  The result is bit-identical
+    to an uninterrupted Scene.render(cfg): frames are keyed by (seed, frame index) and added in
+    index order."""
+    done, accum = 0, np.zeros((cfg.h, cfg.w, 3), np.float64)
+    if os.path.exists(path):
+        accum, done, seed = load_checkpoint(path)
+        if accum.shape != (cfg.h, cfg.w, 3) or seed != cfg.seed:
+            raise ValueError(f"{path}: checkpoint of a different render ({accum.shape[1]}x{accum.shape[0]}, seed {seed})")
+    total = cfg.samples_pr_pixel
+    while done < total:
+        n = min(every, total - done)
+        scene.render(cfg, accum, sample_begin=done, sample_count=n)
+        done += n
+        save_checkpoint(path, accum, done, cfg.seed)
+    return accum
+
+
 def decode_png(path: str) -> np.ndarray:
     w, h = C.c_uint32(), C.c_uint32()
     p = C.POINTER(C.c_uint8)()

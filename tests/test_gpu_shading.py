@@ -190,3 +190,20 @@ def test_stats_counters(trio):
     k = st1["kernel"]
     assert k["path"]["launches"] == 3 and k["extend"]["launches"] == 0 and k["shade"]["launches"] == 0
     assert st1["rays"] == st["rays"]
+
+
+def test_progressive_checkpoint_resume_is_bit_identical(trio, tmp_path):
+    # N1: a render interrupted after 5 of 12 frames and resumed from its checkpoint equals the
+    # uninterrupted one bit for bit
+    data, scene, oracle = trio("CornellBox")
+    cfg = pt.Config(dim=72, samples_pr_pixel=12, seed=21)
+    whole = scene.render(cfg)
+    path = str(tmp_path / "cornell.ckpt")
+    part = pt.Config(dim=72, samples_pr_pixel=5, seed=21)
+    pt.render_progressive(scene, part, path, every=2)          # "crashes" after frames 0..4
+    _, frames, _ = pt.load_checkpoint(path)
+    assert frames == 5
+    resumed = pt.render_progressive(scene, cfg, path, every=4)
+    assert resumed.tobytes() == whole.tobytes()
+    with pytest.raises(ValueError):
+        pt.render_progressive(scene, pt.Config(dim=72, samples_pr_pixel=12, seed=22), path)

@@ -243,3 +243,45 @@ def test_host_rng_matches_the_oracle():
         args = (int(rng.integers(0, 2**63)), int(rng.integers(0, 2**32)), int(rng.integers(0, 2**40)),
                 int(rng.integers(0, 62)), int(rng.integers(0, 3)))
         assert pt.rng_uniform2(*args) == O.rng_uniform2(*args)
+
+
+def test_checkpoint_roundtrip_and_damage(tmp_path):
+    # the running sums + frame count on disk, bit for bit, and damage is detected
+    rng = np.random.default_rng(3)
+    acc = rng.random((37, 53, 3)) * 1e3
+    acc[0, 0] = [np.inf, -0.0, 5e-324]
+    path = str(tmp_path / "run.ckpt")
+    pt.save_checkpoint(path, acc, frames=1234567890123, seed=2**63 + 5)
+    back, frames, seed = pt.load_checkpoint(path)
+    assert back.tobytes() == acc.tobytes() and frames == 1234567890123 and seed == 2**63 + 5
+    assert not (tmp_path / "run.ckpt.tmp").exists()
+    raw = bytearray(open(path, "rb").read())
+    assert len(raw) == 48 + acc.nbytes
+    flipped = bytearray(raw)
+    flipped[48 + 1000] ^= 1
+    open(path, "wb").write(flipped)
+    with pytest.raises(pt.PtError, match="checksum"):
+        pt.load_checkpoint(path)
+    open(path, "wb").write(raw[:-8])
+    with pytest.raises(pt.PtError, match="truncated"):
+        pt.load_checkpoint(path)
+    open(path, "wb").write(b"P3\n1 1\n255\n0 0 0\n" + bytes(64))
+    with pytest.raises(pt.PtError, match="not a checkpoint"):
+        pt.load_checkpoint(path)
+    with pytest.raises(pt.PtError):
+        pt.load_checkpoint(str(tmp_path / "missing.ckpt"))
+
+
+def test_parallel_bvh_build_is_independent_of_thread_count(monkeypatch):
+    # the 10 M-triangle scene is built by worker threads; the tree must be the same
+    # array whatever the thread count (serial std::partition vs. the stable parallel partition,
+    # subtree splicing)
+    from pathtracer_amd.synthetic import heightfield_box
+    data = heightfield_box(cells=260)               # 135,210 triangles: above the parallel threshold
+    out = []
+    for threads in ("1", "2", "7"):
+        monkeypatch.setenv("PT_BVH_THREADS", threads)
+        nodes, order, depth = pt.bvh_build(data.verts, data.tris)
+        out.append((nodes.tobytes(), order.tobytes(), depth))
+    assert out[0] == out[1] == out[2]
+    assert sorted(np.frombuffer(out[0][1], np.uint32).tolist()) == list(range(data.n_tris))
