@@ -36,21 +36,31 @@ typedef enum pt_status {
     PT_ERR_UNSUPPORTED = -5  /* e.g. non power-of-two texture (mipmap.rs:86-89 panics) */
 } pt_status;
 
-/* material kinds: material.rs:31-58 (Lambertian), microfacet.rs:9-94 (Glossy<Beckmann>) */
-enum { PT_MAT_LAMBERT = 0, PT_MAT_GLOSSY = 1 };
+/* material kinds: material.rs:31-58 (Lambertian), microfacet.rs:9-94 (Glossy<Beckmann>); Mirror and
+ * Transparent are the two specular models of the reference's legacy integrator (commented
+ * `shade()`, main.rs:117-142,178-185; material.rs:116-133), SURVEY.md §8f N3 */
+enum { PT_MAT_LAMBERT = 0, PT_MAT_GLOSSY = 1, PT_MAT_MIRROR = 2, PT_MAT_TRANSPARENT = 3 };
 
 /* One material.  Values arrive as f32 from the MTL parser and are widened to f64 exactly as
  * obj.rs:66-69 does (Vec3::from([f32;3]), vec3.rs:187-191).
  *   LAMBERT: color = Kd, emission = Ka (obj.rs:66-69); tex >= 0 replaces color by the mip-mapped
  *            lookup of material.rs:100-111.
  *   GLOSSY : color = reflectance (Kd), roughness = Beckmann width (Ns; clamped to >= 1e-5 by
- *            microfacet.rs:125); emission is ignored (microfacet.rs:33-35 returns zero). */
+ *            microfacet.rs:125); emission is ignored (microfacet.rs:33-35 returns zero).
+ *   MIRROR : wi = d.reflect(n) (main.rs:179, vec3.rs:138-140), radiance passes unchanged; no
+ *            emission (the legacy branch returns only the reflected radiance).
+ *   TRANSPARENT: dielectric of index `ior` in air (FresnelDielectric::new(ior), microfacet.rs:
+ *            306-358; material.rs:116-124 uses 1.5).  The legacy code traces both the reflected
+ *            and the refracted ray and blends them R : 1-R (main.rs:117-142); in the path loop one
+ *            of the two is followed, reflection with probability R (first draw of the bounce), so
+ *            the expectation is the legacy value and the throughput is unchanged.  No emission. */
 typedef struct pt_material {
     float color[3];
     float emission[3];
     float roughness;
     int32_t kind; /* PT_MAT_* */
     int32_t tex;  /* index into pt_scene_desc.texs, or -1 */
+    float ior;    /* TRANSPARENT only */
 } pt_material;
 
 /* 8-bit RGB image, tightly packed, top row first (the order image::open(..).to_rgb() yields,
@@ -115,6 +125,9 @@ typedef struct pt_ray {
 enum {
     PT_FLAG_USE_DIFFS = 1u << 0, /* CONFIG.use_diffs, default true (main.rs:350) */
     PT_FLAG_NEE = 1u << 1,       /* next-event estimation against emissive triangles (+MIS) */
+    PT_FLAG_RUSSIAN_ROULETTE = 1u << 3, /* legacy integrator main.rs:85-111: from the 5th path vertex
+                                         * on a Lambertian vertex continues with probability
+                                         * mean(albedo) and the throughput is divided by it */
     PT_FLAG_DROP_NONFINITE = 1u << 2 /* drop NaN/inf samples instead of accumulating them
                                         (deviation from main.rs:434-436; off by default) */
 };
@@ -237,7 +250,9 @@ typedef struct pt_model pt_model;
 int pt_load_obj(const char* obj_path, uint32_t flags, pt_model** out);
 enum {
     PT_LOAD_GLOSSY = 1u << 0,   /* wire illum 2 -> Glossy(Ns) as the commented obj.rs:30-53 intends */
-    PT_LOAD_TEXTURES = 1u << 1  /* wire map_Kd -> MipMap (obj.rs:41-47) */
+    PT_LOAD_TEXTURES = 1u << 1, /* wire map_Kd -> MipMap (obj.rs:41-47) */
+    PT_LOAD_SPECULAR = 1u << 2  /* wire illum 3 -> Mirror, illum 4 -> Transparent(Ni, 1.5 if absent)
+                                 * (IlluminationModel::from, material.rs:157-170) */
 };
 const pt_scene_desc* pt_model_desc(const pt_model* model);
 uint32_t pt_model_count(const pt_model* model);               /* tobj models (= reference Geometry count) */

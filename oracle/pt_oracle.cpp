@@ -105,7 +105,7 @@ inline void philox4x32_10(const uint32_t key[2], const uint32_t ctr[4], uint32_t
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-enum { STREAM_BRDF = 0, STREAM_LIGHT = 1, STREAM_JITTER = 2 };
+enum { STREAM_BRDF = 0, STREAM_LIGHT = 1, STREAM_JITTER = 2, STREAM_ROULETTE = 3 };
 inline void uniform2(uint64_t seed, uint32_t pixel, uint64_t sample, uint32_t bounce, uint32_t stream,
                      double out[2]) {
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
@@ -349,8 +349,10 @@ struct Material {
     V3 color, emission;
     double roughness;
     int tex;
+    double ior;
 };
 
+// pdf < 0 marks a specular (delta) sample: f is then the throughput factor itself
 struct BrdfSample {
     V3 f, wi;
     double pdf;
@@ -658,10 +660,20 @@ inline V3 get_diffuse(const Scene& sc, const Material& m, const Surface& s) {
 inline BrdfSample sample_brdf(const Scene& sc, const Material& m, const Surface& s, V3 ray_dir, double xi1,
                               double xi2) {
     if (m.kind == PT_MAT_GLOSSY) return glossy_sample(m.color, m.roughness, ray_dir, s.normal, xi1, xi2);
+    if (m.kind == PT_MAT_MIRROR)  // main.rs:178-185
+        return {v3(1, 1, 1), reflect(ray_dir, s.normal), -1.};
+    if (m.kind == PT_MAT_TRANSPARENT) {  // main.rs:117-142, one of the two branches by Fresnel weight
+        double cos_theta = dot(-ray_dir, s.normal);
+        double eta = cos_theta < 0. ? m.ior / 1. : 1. / m.ior;  // FresnelDielectric::eta, microfacet.rs:318-326
+        double fresnel_r = dielectric(m.ior, cos_theta);
+        V3 normal = cos_theta < 0. ? -s.normal : s.normal;
+        if (xi1 < fresnel_r) return {v3(1, 1, 1), reflect(ray_dir, normal), -1.};
+        return {v3(1, 1, 1), refract(ray_dir, normal, eta), -1.};
+    }
     return lambertian_sample(get_diffuse(sc, m, s), s.normal, xi1, xi2);
 }
 inline V3 emission_of(const Material& m) {
-    return m.kind == PT_MAT_GLOSSY ? v3(0, 0, 0) : m.emission;  // microfacet.rs:33-35
+    return m.kind == PT_MAT_LAMBERT ? m.emission : v3(0, 0, 0);  // microfacet.rs:33-35; legacy specular branches add none
 }
 
 inline Hit trace(const Scene& sc, const Ray& r, bool bvh) {
@@ -681,6 +693,7 @@ inline double brdf_pdf_dir(const Material& m, V3 wo, V3 wi, V3 n) {
         double p = glossy_pdf_dir(m.roughness, wo, wi, n);
         return p > 0. ? p : 0.;
     }
+    if (m.kind != PT_MAT_LAMBERT) return 0.;  // specular: a light sample has zero weight
     double c = dot(n, wi);
     return c > 0. ? c * FRAC_1_PI : 0.;
 }
@@ -723,7 +736,8 @@ inline V3 render(const Scene& sc, double x, double y, double pdx, double pdy, ui
         V3 le = emission_of(m);
         if (nee && bounce > 0 && (le.x != 0. || le.y != 0. || le.z != 0.)) {
             double p_l = light_pdf_dir(sc, tr, trace_ray.origin, trace_ray.direction, h.t);
-            double wgt = prev_pdf > 0. ? prev_pdf / (prev_pdf + p_l) : 0.;
+            // prev_pdf < 0: the ray came from a specular vertex, which no light sample can reach
+            double wgt = prev_pdf > 0. ? prev_pdf / (prev_pdf + p_l) : (prev_pdf < 0. ? 1. : 0.);
             color_result = color_result + accumulated_pdf * le * wgt;
         } else {
             color_result = color_result + accumulated_pdf * le;
@@ -765,11 +779,27 @@ inline V3 render(const Scene& sc, double x, double y, double pdx, double pdy, ui
             }
         }
 
+        // Russian roulette of the legacy integrator (main.rs:85-93,110): trace_depth = bounce + 1
+        double luminance = 1.;
+        if ((P.flags & PT_FLAG_RUSSIAN_ROULETTE) && m.kind == PT_MAT_LAMBERT && bounce + 1 >= 5) {
+            V3 color = get_diffuse(sc, m, surface);
+            luminance = (color.x + color.y + color.z) / 3.;
+            double rr[2];
+            uniform2(P.seed, pixel, sample, bounce, STREAM_ROULETTE, rr);
+            if (luminance < rr[0]) return color_result;
+        }
+
         double xi[2];
         uniform2(P.seed, pixel, sample, bounce, STREAM_BRDF, xi);
         BrdfSample bs = sample_brdf(sc, m, surface, trace_ray.direction, xi[0], xi[1]);
-        accumulated_pdf = accumulated_pdf * (bs.f * std::fabs(dot(bs.wi, surface.normal)) / bs.pdf);
-        prev_pdf = bs.pdf > 0. ? bs.pdf : 0.;
+        if (bs.pdf < 0.) {  // specular
+            accumulated_pdf = accumulated_pdf * bs.f;
+            prev_pdf = -1.;
+        } else {
+            accumulated_pdf = accumulated_pdf * (bs.f * std::fabs(dot(bs.wi, surface.normal)) / bs.pdf);
+            prev_pdf = bs.pdf > 0. ? bs.pdf : 0.;
+        }
+        if (luminance != 1.) accumulated_pdf = accumulated_pdf / luminance;
         trace_ray = Ray(surface.position, bs.wi);
     }
     return color_result;
@@ -800,6 +830,7 @@ int orc_scene_create(const pt_scene_desc* d, orc_scene** out) {
         mm.emission = v3((double)m.emission[0], (double)m.emission[1], (double)m.emission[2]);
         mm.roughness = (double)m.roughness;
         mm.tex = m.tex;
+        mm.ior = (double)m.ior;
         sc.mats.push_back(mm);
     }
     for (uint32_t i = 0; i < d->n_texs; ++i) {

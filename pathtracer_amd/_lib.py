@@ -14,17 +14,17 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpt_hip.so")
 
 PT_MISS = 0xFFFFFFFF
 PT_OK, PT_ERR_INVALID, PT_ERR_NOMEM, PT_ERR_DEVICE, PT_ERR_IO, PT_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
-PT_MAT_LAMBERT, PT_MAT_GLOSSY = 0, 1
+PT_MAT_LAMBERT, PT_MAT_GLOSSY, PT_MAT_MIRROR, PT_MAT_TRANSPARENT = 0, 1, 2, 3
 PT_BVH_EMPTY = 0x7FFFFFFF
-PT_FLAG_USE_DIFFS, PT_FLAG_NEE, PT_FLAG_DROP_NONFINITE = 1, 2, 4
-PT_LOAD_GLOSSY, PT_LOAD_TEXTURES = 1, 2
+PT_FLAG_USE_DIFFS, PT_FLAG_NEE, PT_FLAG_DROP_NONFINITE, PT_FLAG_RUSSIAN_ROULETTE = 1, 2, 4, 8
+PT_LOAD_GLOSSY, PT_LOAD_TEXTURES, PT_LOAD_SPECULAR = 1, 2, 4
 PT_K_GENERATE, PT_K_EXTEND, PT_K_SHADE, PT_K_SHADOW, PT_K_ACCUMULATE, PT_K_PATH, PT_K_COUNT = 0, 1, 2, 3, 4, 5, 6
 KERNEL_NAMES = ("generate", "extend", "shade", "shadow", "accumulate", "path")
 
 
 class pt_material(C.Structure):
     _fields_ = [("color", C.c_float * 3), ("emission", C.c_float * 3), ("roughness", C.c_float),
-                ("kind", C.c_int32), ("tex", C.c_int32)]
+                ("kind", C.c_int32), ("tex", C.c_int32), ("ior", C.c_float)]
 
 
 class pt_texture(C.Structure):

@@ -336,7 +336,8 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
     if ((d->n_mats && !d->mats) || (d->n_texs && !d->texs)) { set_error("mats/texs missing"); return PT_ERR_INVALID; }
     for (uint32_t i = 0; i < d->n_mats; ++i) {
         const pt_material& m = d->mats[i];
-        if (m.kind != PT_MAT_LAMBERT && m.kind != PT_MAT_GLOSSY) { set_error("material %u: bad kind", i); return PT_ERR_INVALID; }
+        if (m.kind < PT_MAT_LAMBERT || m.kind > PT_MAT_TRANSPARENT) { set_error("material %u: bad kind", i); return PT_ERR_INVALID; }
+        if (m.kind == PT_MAT_TRANSPARENT && !(m.ior > 0.f)) { set_error("material %u: transparent needs ior > 0", i); return PT_ERR_INVALID; }
         if (m.tex >= (int32_t)d->n_texs) { set_error("material %u: texture index out of range", i); return PT_ERR_INVALID; }
     }
     for (uint32_t i = 0; i < d->n_tris; ++i) {
@@ -417,6 +418,7 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
         mats[i].width = std::fmax((double)m.roughness, 1e-5);  // microfacet.rs:125
         mats[i].kind = m.kind;
         mats[i].tex = m.tex;
+        mats[i].ior = (double)m.ior;
     }
     if ((rc = upload(s->d_mats, mats.data(), mats.size())) != PT_OK) return rc;
 
@@ -444,7 +446,7 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
     double acc = 0.;
     for (uint32_t g = 0; g < d->n_tris; ++g) {
         const ptd::Material& m = mats[d->tri_material ? d->tri_material[g] : 0];
-        if (m.kind == PT_MAT_GLOSSY) continue;
+        if (m.kind != PT_MAT_LAMBERT) continue;  // only Lambertian surfaces emit (microfacet.rs:33-35; legacy specular branches)
         if (m.emission[0] == 0. && m.emission[1] == 0. && m.emission[2] == 0.) continue;
         H3 v[3];
         for (int k = 0; k < 3; ++k) {

@@ -20,6 +20,7 @@ struct Material {
     double width;  // Beckmann width = max(roughness, 1e-5) (microfacet.rs:125)
     int32_t kind;
     int32_t tex;
+    double ior;  // TRANSPARENT
 };
 
 struct Texture {

@@ -56,7 +56,7 @@ __device__ __forceinline__ D3 rotate_to(D3 self, D3 n) {
 
 // ------------------------------------------------------------------------------------------------
 // Philox4x32-10, counter = (pixel, sample_lo, sample_hi, bounce | stream << 24), key = seed.
-enum { STREAM_BRDF = 0, STREAM_LIGHT = 1, STREAM_JITTER = 2 };
+enum { STREAM_BRDF = 0, STREAM_LIGHT = 1, STREAM_JITTER = 2, STREAM_ROULETTE = 3 };
 __host__ __device__ __forceinline__ void uniform2(uint64_t seed, uint32_t pixel, uint64_t sample, uint32_t bounce,
                                                   uint32_t stream, double& u0, double& u1) {
     uint32_t c0 = pixel, c1 = (uint32_t)sample, c2 = (uint32_t)(sample >> 32), c3 = bounce | (stream << 24);
@@ -619,6 +619,40 @@ struct Brdf {
     D3 f, wi;
     double pdf;
 };
+// vec3.rs:142-146
+__device__ __forceinline__ D3 refract(D3 self, D3 normal, double eta) {
+    double cos_i = -dot(self, normal);
+    double sin_sqr = eta * eta * (1. - cos_i * cos_i);
+    return self * eta + normal * (eta * cos_i - sqrt(1. - sin_sqr));
+}
+// FresnelDielectric::dielectric for an object of index `ior` in air (microfacet.rs:306-358)
+__device__ __forceinline__ double dielectric(double ior, double cos_theta_i) {
+    double ior_i = 1., ior_t = ior;
+    if (cos_theta_i < 0.) {  // inside: the object's medium is the incident one
+        ior_i = ior; ior_t = 1.;
+        cos_theta_i = fabs(cos_theta_i);
+    }
+    double eta = ior_i / ior_t;
+    double sin_theta_i = sqrt(fmax(0., 1. - cos_theta_i * cos_theta_i));
+    double sin_theta_t = ior_i / ior_t * sin_theta_i;
+    double sin_theta_t_sqr = eta * eta * (1. - cos_theta_i * cos_theta_i);
+    if (sin_theta_t >= 1.) return 1.;  // total internal reflection
+    double cos_theta_t = sqrt(fmax(0., 1. - sin_theta_t_sqr));
+    double fresnel_par = ((ior_t * cos_theta_i) - (ior_i * cos_theta_t)) / ((ior_t * cos_theta_i) + (ior_i * cos_theta_t));
+    double fresnel_perp = ((ior_i * cos_theta_i) - (ior_t * cos_theta_t)) / ((ior_i * cos_theta_i) + (ior_t * cos_theta_t));
+    return (fresnel_par * fresnel_par + fresnel_perp * fresnel_perp) * 0.5;
+}
+// Mirror (main.rs:178-185) and Transparent (main.rs:117-142; one of its two branches, reflection
+// with probability R from the bounce's first draw).  The radiance passes unchanged either way.
+__device__ __forceinline__ D3 specular_sample(const Material& m, D3 ray_dir, D3 n, double xi1) {
+    if (m.kind == PT_MAT_MIRROR) return reflect(ray_dir, n);
+    double cos_theta = dot(-ray_dir, n);
+    double eta = cos_theta < 0. ? m.ior / 1. : 1. / m.ior;  // FresnelDielectric::eta, microfacet.rs:318-326
+    double fresnel_r = dielectric(m.ior, cos_theta);
+    D3 normal = cos_theta < 0. ? -n : n;
+    if (xi1 < fresnel_r) return reflect(ray_dir, normal);
+    return refract(ray_dir, normal, eta);
+}
 // material.rs:9-23 + 37-58
 __device__ __forceinline__ Brdf lambertian_sample(D3 color, D3 n, double xi1, double xi2) {
     double cos_theta = sqrt(xi1);
@@ -756,7 +790,7 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
     } else if (!kNeedRay) {
         uint32_t mat = (uint32_t)__float_as_int(sc.tris[(size_t)leaf * 3 + 1].w);
         const Material& m = sc.mats[mat];
-        D3 le = (!PLAIN && m.kind == PT_MAT_GLOSSY) ? mk(0., 0., 0.) : ld3(m.emission);  // microfacet.rs:33-35
+        D3 le = (!PLAIN && m.kind != PT_MAT_LAMBERT) ? mk(0., 0., 0.) : ld3(m.emission);  // microfacet.rs:33-35; specular: none
         add = T * le;  // main.rs:307
     } else {
         const double t = t_hit;
@@ -765,7 +799,7 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
         D3 position, normal;
         hit_geometry(sc, leaf, o, d, t, tr, mat, position, normal);
         const Material& m = sc.mats[mat];
-        D3 le = (!PLAIN && m.kind == PT_MAT_GLOSSY) ? mk(0., 0., 0.) : ld3(m.emission);  // microfacet.rs:33-35
+        D3 le = (!PLAIN && m.kind != PT_MAT_LAMBERT) ? mk(0., 0., 0.) : ld3(m.emission);  // microfacet.rs:33-35; specular: none
         add = T * le;  // main.rs:307
         if (NEE && !FIRST && (le.x != 0. || le.y != 0. || le.z != 0.)) {
             // MIS weight of a BRDF-sampled hit on a light (balance heuristic)
@@ -773,13 +807,13 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
             double cos_l = fabs(dot(ln, d));
             double p_l = cos_l <= 0. ? 0. : t * t / (sc.light_area * cos_l);
             double pp = in.prev_pdf[i];
-            double wgt = pp > 0. ? pp / (pp + p_l) : 0.;
+            double wgt = pp > 0. ? pp / (pp + p_l) : (pp < 0. ? 1. : 0.);  // pp < 0: specular predecessor
             add = T * le * wgt;
         }
         if (!LAST) {
             D3 diffuse = mk(0., 0., 0.);
             if (PLAIN) diffuse = ld3(m.color);
-            else if (m.kind != PT_MAT_GLOSSY) diffuse = diffuse_of(sc, m, tr, leaf, o, d, position, normal, fr, FIRST, pixel, s);
+            else if (m.kind == PT_MAT_LAMBERT) diffuse = diffuse_of(sc, m, tr, leaf, o, d, position, normal, fr, FIRST, pixel, s);
             if (NEE && sc.n_lights) {
                 double r0, r1;
                 uniform2(fr.seed, pixel, sample, bounce, STREAM_LIGHT, r0, r1);
@@ -805,6 +839,8 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
                 if ((!PLAIN && m.kind == PT_MAT_GLOSSY)) {
                     double pg = glossy_pdf_dir(m.width, wo, wl, normal);
                     p_b = pg > 0. ? pg : 0.;
+                } else if (!PLAIN && m.kind != PT_MAT_LAMBERT) {
+                    p_b = 0.;  // specular: a light sample has zero weight
                 } else {
                     double c = dot(normal, wl);
                     p_b = c > 0. ? c * PT_FRAC_1_PI : 0.;
@@ -822,15 +858,33 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
                     r.shadow = true;
                 }
             }
-            double xi1, xi2;
-            uniform2(fr.seed, pixel, sample, bounce, STREAM_BRDF, xi1, xi2);
-            Brdf bs = (!PLAIN && m.kind == PT_MAT_GLOSSY) ? glossy_sample(m.width, ld3(m.color), d, normal, xi1, xi2)
-                                              : lambertian_sample(diffuse, normal, xi1, xi2);
-            r.n_T = T * (bs.f * fabs(dot(bs.wi, normal)) / bs.pdf);  // main.rs:311
-            r.n_o = position;                                        // main.rs:314
-            r.n_d = bs.wi;
-            r.n_pdf = bs.pdf > 0. ? bs.pdf : 0.;
-            r.alive = true;
+            // Russian roulette of the legacy integrator (main.rs:85-93,110): trace_depth = bounce + 1
+            double luminance = 1.;
+            bool absorbed = false;
+            if ((fr.flags & PT_FLAG_RUSSIAN_ROULETTE) && bounce + 1 >= 5 && (PLAIN || m.kind == PT_MAT_LAMBERT)) {
+                luminance = (diffuse.x + diffuse.y + diffuse.z) / 3.;
+                double q0, q1;
+                uniform2(fr.seed, pixel, sample, bounce, STREAM_ROULETTE, q0, q1);
+                absorbed = luminance < q0;
+            }
+            if (!absorbed) {
+                double xi1, xi2;
+                uniform2(fr.seed, pixel, sample, bounce, STREAM_BRDF, xi1, xi2);
+                if (!PLAIN && m.kind >= PT_MAT_MIRROR) {
+                    r.n_T = T;  // specular: radiance passes unchanged
+                    r.n_d = specular_sample(m, d, normal, xi1);
+                    r.n_pdf = -1.;
+                } else {
+                    Brdf bs = (!PLAIN && m.kind == PT_MAT_GLOSSY) ? glossy_sample(m.width, ld3(m.color), d, normal, xi1, xi2)
+                                                      : lambertian_sample(diffuse, normal, xi1, xi2);
+                    r.n_T = T * (bs.f * fabs(dot(bs.wi, normal)) / bs.pdf);  // main.rs:311
+                    r.n_d = bs.wi;
+                    r.n_pdf = bs.pdf > 0. ? bs.pdf : 0.;
+                }
+                if (luminance != 1.) r.n_T = r.n_T / luminance;
+                r.n_o = position;  // main.rs:314
+                r.alive = true;
+            }
         }
     }
     // color_result += add.  Adding +-0 never changes the sum (it starts at +0), NaN != 0 is true.
@@ -1000,12 +1054,14 @@ __global__ void k_sample_brdf(Scene sc, Frame fr, uint32_t bounce, const double*
     const Material& m = sc.mats[mat];
     uint32_t pixel = pixel_in[i];
     D3 diffuse = mk(0., 0., 0.);
-    if (m.kind != PT_MAT_GLOSSY) diffuse = diffuse_of(sc, m, tr, leaf, o, d, position, normal, fr, bounce == 0, pixel, 0);
+    if (m.kind == PT_MAT_LAMBERT) diffuse = diffuse_of(sc, m, tr, leaf, o, d, position, normal, fr, bounce == 0, pixel, 0);
     double xi1, xi2;
     uniform2(fr.seed, pixel, fr.sample_base, bounce, STREAM_BRDF, xi1, xi2);
-    Brdf bs = m.kind == PT_MAT_GLOSSY ? glossy_sample(m.width, ld3(m.color), d, normal, xi1, xi2)
-                                      : lambertian_sample(diffuse, normal, xi1, xi2);
-    D3 le = m.kind == PT_MAT_GLOSSY ? mk(0., 0., 0.) : ld3(m.emission);
+    Brdf bs;
+    if (m.kind >= PT_MAT_MIRROR) bs = {mk(1., 1., 1.), specular_sample(m, d, normal, xi1), -1.};  // pdf < 0: specular
+    else if (m.kind == PT_MAT_GLOSSY) bs = glossy_sample(m.width, ld3(m.color), d, normal, xi1, xi2);
+    else bs = lambertian_sample(diffuse, normal, xi1, xi2);
+    D3 le = m.kind != PT_MAT_LAMBERT ? mk(0., 0., 0.) : ld3(m.emission);
     f[3 * i] = bs.f.x; f[3 * i + 1] = bs.f.y; f[3 * i + 2] = bs.f.z;
     wi[3 * i] = bs.wi.x; wi[3 * i + 1] = bs.wi.y; wi[3 * i + 2] = bs.wi.z;
     pdf[i] = bs.pdf;

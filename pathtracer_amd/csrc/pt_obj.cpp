@@ -33,6 +33,7 @@ struct MtlEntry {
     std::string name;
     float ambient[3] = {0, 0, 0}, diffuse[3] = {0, 0, 0}, specular[3] = {0, 0, 0};
     float shininess = 0.f;
+    float optical_density = 0.f;  // Ni
     std::string diffuse_texture;
     bool has_illum = false;
     int illum = 0;
@@ -93,6 +94,7 @@ bool load_mtl(const std::string& path, std::vector<MtlEntry>& mats, std::map<std
         else if (k == "Kd") parse_floats(w, 3, cur.diffuse);
         else if (k == "Ks") parse_floats(w, 3, cur.specular);
         else if (k == "Ns") parse_floats(w, 1, &cur.shininess);
+        else if (k == "Ni") parse_floats(w, 1, &cur.optical_density);
         else if (k == "map_Kd") cur.diffuse_texture = rest_of_line(line, "map_Kd");
         else if (k == "illum") {
             if (w.size() > 1) { cur.has_illum = true; cur.illum = std::atoi(w[1].c_str()); }
@@ -288,6 +290,11 @@ int pt_load_obj(const char* obj_path, uint32_t flags, pt_model** out) {
             pm.roughness = m.shininess;
             if (want_glossy && m.illum == 2) {  // obj.rs:38-40 (commented wiring): Glossy::new(Ns, _, Kd)
                 pm.kind = PT_MAT_GLOSSY;
+                for (int c = 0; c < 3; ++c) pm.emission[c] = 0.f;
+            } else if ((flags & PT_LOAD_SPECULAR) && (m.illum == 3 || m.illum == 4)) {
+                // IlluminationModel::from (material.rs:157-170): 3 = Mirror, 4 = Transparent
+                pm.kind = m.illum == 3 ? PT_MAT_MIRROR : PT_MAT_TRANSPARENT;
+                pm.ior = m.optical_density > 0.f ? m.optical_density : 1.5f;  // Material::glass(), material.rs:117
                 for (int c = 0; c < 3; ++c) pm.emission[c] = 0.f;
             } else if (want_tex && !m.diffuse_texture.empty()) {  // obj.rs:41-47
                 std::string cand[3] = {m.diffuse_texture, dir + "/" + m.diffuse_texture, dir + "/" + base_of(m.diffuse_texture)};

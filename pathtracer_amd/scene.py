@@ -24,7 +24,7 @@ RAY_DTYPE = np.dtype([("o", "<f8", 3), ("d", "<f8", 3), ("t_min", "<f8"), ("t_ma
 assert RAY_DTYPE.itemsize == C.sizeof(L.pt_ray)
 NODE_DTYPE = np.dtype([("bounds", "<f4", 12), ("child", "<i4", 2), ("pad", "<u4", 2)])
 MATERIAL_DTYPE = np.dtype([("color", "<f4", 3), ("emission", "<f4", 3), ("roughness", "<f4"),
-                           ("kind", "<i4"), ("tex", "<i4")])
+                           ("kind", "<i4"), ("tex", "<i4"), ("ior", "<f4")])
 assert MATERIAL_DTYPE.itemsize == C.sizeof(L.pt_material)
 
 
@@ -61,6 +61,7 @@ class Config:
     seed: int = 1
     nee: bool = False
     drop_nonfinite: bool = False
+    russian_roulette: bool = False  # legacy integrator main.rs:85-93
     spp_per_batch: int = 0
 
     @property
@@ -79,6 +80,8 @@ class Config:
             f |= L.PT_FLAG_NEE
         if self.drop_nonfinite:
             f |= L.PT_FLAG_DROP_NONFINITE
+        if self.russian_roulette:
+            f |= L.PT_FLAG_RUSSIAN_ROULETTE
         return f
 
     def params(self, sample_begin: int, sample_count: int, tile=None) -> L.pt_render_params:
@@ -145,10 +148,11 @@ class SceneData:
         return d
 
 
-def load_obj(obj_name: str, glossy: bool = False, textures: bool = False) -> SceneData:
-    """obj.rs:13-107 ``load_obj``; ``glossy`` / ``textures`` enable the wiring the reference has
-    commented out (obj.rs:30-53)."""
-    flags = (L.PT_LOAD_GLOSSY if glossy else 0) | (L.PT_LOAD_TEXTURES if textures else 0)
+def load_obj(obj_name: str, glossy: bool = False, textures: bool = False, specular: bool = False) -> SceneData:
+    """obj.rs:13-107 ``load_obj``; ``glossy`` / ``textures`` / ``specular`` enable the wiring the
+    reference has commented out (obj.rs:30-53; illum 3 = Mirror, 4 = Transparent)."""
+    flags = ((L.PT_LOAD_GLOSSY if glossy else 0) | (L.PT_LOAD_TEXTURES if textures else 0)
+             | (L.PT_LOAD_SPECULAR if specular else 0))
     h = C.c_void_p()
     L.check(L.lib.pt_load_obj(os.fsencode(obj_name), flags, C.byref(h)))
     try:
@@ -328,11 +332,12 @@ CAMERAS = {
 }
 
 
-def scene_data(name: str, glossy: Optional[bool] = None, textures: bool = False, models_dir: str = MODELS_DIR) -> SceneData:
+def scene_data(name: str, glossy: Optional[bool] = None, textures: bool = False, models_dir: str = MODELS_DIR,
+               specular: bool = False) -> SceneData:
     """Loads models/<name>.obj with the camera of SURVEY.md F6 and a black background (scene.rs:177)."""
     if glossy is None:
         glossy = name == "glossy_planes"
-    data = load_obj(os.path.join(models_dir, name + ".obj"), glossy=glossy, textures=textures)
+    data = load_obj(os.path.join(models_dir, name + ".obj"), glossy=glossy, textures=textures, specular=specular)
     data.camera = CAMERAS[name]
     data.background = (0.0, 0.0, 0.0)
     return data

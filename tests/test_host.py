@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_the_header():
     assert C.sizeof(L.pt_bvh_node) == 64
     assert C.sizeof(L.pt_ray) == 64
-    assert C.sizeof(L.pt_material) == 36
+    assert C.sizeof(L.pt_material) == 40
     assert C.sizeof(L.pt_render_params) == 56
     assert C.sizeof(L.pt_camera) == 80
 
