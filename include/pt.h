@@ -39,7 +39,7 @@ typedef enum pt_status {
 /* material kinds: material.rs:31-58 (Lambertian), microfacet.rs:9-94 (Glossy<Beckmann>); Mirror and
  * Transparent are the two specular models of the reference's legacy integrator (commented
  * `shade()`, main.rs:117-142,178-185; material.rs:116-133), SURVEY.md §8f N3 */
-enum { PT_MAT_LAMBERT = 0, PT_MAT_GLOSSY = 1, PT_MAT_MIRROR = 2, PT_MAT_TRANSPARENT = 3 };
+enum { PT_MAT_LAMBERT = 0, PT_MAT_GLOSSY = 1, PT_MAT_MIRROR = 2, PT_MAT_TRANSPARENT = 3, PT_MAT_GLOSSY_GGX = 4 };
 
 /* One material.  Values arrive as f32 from the MTL parser and are widened to f64 exactly as
  * obj.rs:66-69 does (Vec3::from([f32;3]), vec3.rs:187-191).
@@ -47,6 +47,8 @@ enum { PT_MAT_LAMBERT = 0, PT_MAT_GLOSSY = 1, PT_MAT_MIRROR = 2, PT_MAT_TRANSPAR
  *            lookup of material.rs:100-111.
  *   GLOSSY : color = reflectance (Kd), roughness = Beckmann width (Ns; clamped to >= 1e-5 by
  *            microfacet.rs:125); emission is ignored (microfacet.rs:33-35 returns zero).
+ *   GLOSSY_GGX: the same Glossy with the reference's second distribution, GGX (microfacet.rs:192-243,
+ *            private and never instantiated there); roughness = alpha_g, not clamped.
  *   MIRROR : wi = d.reflect(n) (main.rs:179, vec3.rs:138-140), radiance passes unchanged; no
  *            emission (the legacy branch returns only the reflected radiance).
  *   TRANSPARENT: dielectric of index `ior` in air (FresnelDielectric::new(ior), microfacet.rs:
@@ -251,8 +253,9 @@ int pt_load_obj(const char* obj_path, uint32_t flags, pt_model** out);
 enum {
     PT_LOAD_GLOSSY = 1u << 0,   /* wire illum 2 -> Glossy(Ns) as the commented obj.rs:30-53 intends */
     PT_LOAD_TEXTURES = 1u << 1, /* wire map_Kd -> MipMap (obj.rs:41-47) */
-    PT_LOAD_SPECULAR = 1u << 2  /* wire illum 3 -> Mirror, illum 4 -> Transparent(Ni, 1.5 if absent)
+    PT_LOAD_SPECULAR = 1u << 2, /* wire illum 3 -> Mirror, illum 4 -> Transparent(Ni, 1.5 if absent)
                                  * (IlluminationModel::from, material.rs:157-170) */
+    PT_LOAD_GGX = 1u << 3       /* with PT_LOAD_GLOSSY: illum 2 -> Glossy over GGX instead of Beckmann */
 };
 const pt_scene_desc* pt_model_desc(const pt_model* model);
 uint32_t pt_model_count(const pt_model* model);               /* tobj models (= reference Geometry count) */

@@ -343,6 +343,52 @@ struct Beckmann {
     }
 };
 
+// microfacet.rs:366-381 helpers used by GGX
+inline double tan2_theta(V3 w1, V3 w2) {
+    double c = dot(w1, w2);
+    double cos2 = c * c;
+    double sin2 = std::fmax(0., 1. - cos2);
+    return sin2 / cos2;
+}
+// microfacet.rs:192-243 (the reference's second, never-instantiated distribution)
+struct GGX {
+    double roughness;
+    explicit GGX(double r) : roughness(r) {}
+    V3 sample_microfacet_normal(V3 normal, double xi1, double xi2) const {
+        double tan_theta_sqr = roughness * roughness * xi1 / (1. - xi1);
+        double phi = 2.0 * xi2 * PI;
+        double cos_theta_sqr = 1. / (1. + tan_theta_sqr);
+        double cos_theta = std::sqrt(cos_theta_sqr);
+        double sin_theta = std::sqrt(1. - cos_theta_sqr);
+        V3 hv = v3(sin_theta * std::cos(phi), sin_theta * std::sin(phi), cos_theta);
+        return normalize(rotate_to(hv, normal));
+    }
+    double D(V3 half_vector, V3 macro_normal) const {
+        double cos_theta = dot(half_vector, macro_normal);
+        if (cos_theta <= 0.0) return 0.;
+        double alpha_g_sqr = roughness * roughness;
+        double tan_theta_sqr = tan2_theta(half_vector, macro_normal);
+        if (std::isinf(tan_theta_sqr)) return 0.;
+        double alpha_tan2 = alpha_g_sqr + tan_theta_sqr;
+        double c2 = cos_theta * cos_theta;
+        return alpha_g_sqr / (PI * (c2 * c2) * (alpha_tan2 * alpha_tan2));
+    }
+    double G1(V3 w, V3 vh, V3) const {
+        double cos_theta = dot(w, vh);
+        double alpha_g_sqr = roughness * roughness;
+        double cos_theta_sqr = cos_theta * cos_theta;
+        double tan_theta_sqr = (1. - cos_theta_sqr) / cos_theta_sqr;
+        return 2. / (1. + std::sqrt(1. + alpha_g_sqr * tan_theta_sqr));
+    }
+    double G(V3 wo, V3 wi, V3 n) const {
+        V3 hv = normalize(wi + wo);
+        return G1(wo, hv, n) * G1(wi, hv, n);
+    }
+    double pdf(V3 half_vector, V3 macro_normal) const {
+        return D(half_vector, macro_normal) * std::fabs(dot(half_vector, macro_normal));
+    }
+};
+
 // ---------------------------------------------------------------- materials
 struct Material {
     int kind;
@@ -375,7 +421,8 @@ inline BrdfSample lambertian_sample(V3 color, V3 normal, double xi1, double xi2)
     return {f, sampled_direction, angle * FRAC_1_PI};
 }
 // microfacet.rs:64-93 Glossy::f (fresnel fixed by microfacet.rs:45: ior 32, absorption 0.1, ior_t 1)
-inline V3 glossy_f(const Beckmann& dist, V3 reflectance, V3 wo, V3 wi, V3 normal) {
+template <class Dist>
+inline V3 glossy_f(const Dist& dist, V3 reflectance, V3 wo, V3 wi, V3 normal) {
     V3 wh = normalize(wo + wi);
     double cos_theta_o = std::fabs(dot(wo, normal));
     double cos_theta_i = std::fabs(dot(wi, normal));
@@ -389,9 +436,9 @@ inline V3 glossy_f(const Beckmann& dist, V3 reflectance, V3 wo, V3 wi, V3 normal
     return reflectance * d * g * fresnel / (4. * cos_theta_i * cos_theta_o);
 }
 // microfacet.rs:52-62 Glossy::shade
-inline BrdfSample glossy_sample(V3 reflectance, double roughness, V3 ray_direction, V3 normal,
-                                double xi1, double xi2) {
-    Beckmann dist(roughness);
+template <class Dist>
+inline BrdfSample glossy_sample_with(const Dist& dist, V3 reflectance, V3 ray_direction, V3 normal, double xi1,
+                                     double xi2) {
     V3 wo = -ray_direction;
     V3 half_vector = dist.sample_microfacet_normal(normal, xi1, xi2);
     V3 sampled_wi = reflect(-wo, half_vector);
@@ -399,12 +446,18 @@ inline BrdfSample glossy_sample(V3 reflectance, double roughness, V3 ray_directi
     V3 color = glossy_f(dist, reflectance, wo, sampled_wi, normal);
     return {color, sampled_wi, pdf};
 }
-// microfacet.rs:28-31 Glossy::pdf(out, in, n) as used by NEE's MIS weight
-inline double glossy_pdf_dir(double roughness, V3 wo, V3 wi, V3 normal) {
-    Beckmann dist(roughness);
-    V3 h = normalize(wo + wi);
-    return dist.pdf(h, normal) / (4. * dot(wo, h));
+inline BrdfSample glossy_sample(V3 reflectance, double roughness, V3 ray_direction, V3 normal, double xi1,
+                                double xi2, bool ggx = false) {
+    if (ggx) return glossy_sample_with(GGX(roughness), reflectance, ray_direction, normal, xi1, xi2);
+    return glossy_sample_with(Beckmann(roughness), reflectance, ray_direction, normal, xi1, xi2);
 }
+// microfacet.rs:28-31 Glossy::pdf(out, in, n) as used by NEE's MIS weight
+inline double glossy_pdf_dir(double roughness, V3 wo, V3 wi, V3 normal, bool ggx = false) {
+    V3 h = normalize(wo + wi);
+    if (ggx) return GGX(roughness).pdf(h, normal) / (4. * dot(wo, h));
+    return Beckmann(roughness).pdf(h, normal) / (4. * dot(wo, h));
+}
+inline bool is_glossy(int kind) { return kind == PT_MAT_GLOSSY || kind == PT_MAT_GLOSSY_GGX; }
 
 // ---------------------------------------------------------------- scene
 struct Tri {
@@ -659,7 +712,7 @@ inline V3 get_diffuse(const Scene& sc, const Material& m, const Surface& s) {
 
 inline BrdfSample sample_brdf(const Scene& sc, const Material& m, const Surface& s, V3 ray_dir, double xi1,
                               double xi2) {
-    if (m.kind == PT_MAT_GLOSSY) return glossy_sample(m.color, m.roughness, ray_dir, s.normal, xi1, xi2);
+    if (is_glossy(m.kind)) return glossy_sample(m.color, m.roughness, ray_dir, s.normal, xi1, xi2, m.kind == PT_MAT_GLOSSY_GGX);
     if (m.kind == PT_MAT_MIRROR)  // main.rs:178-185
         return {v3(1, 1, 1), reflect(ray_dir, s.normal), -1.};
     if (m.kind == PT_MAT_TRANSPARENT) {  // main.rs:117-142, one of the two branches by Fresnel weight
@@ -689,8 +742,8 @@ inline Hit trace(const Scene& sc, const Ray& r, bool bvh) {
 // p_l/(p_b+p_l), with p_l in solid angle.  Primary hits see emission unweighted.
 inline double tri_area(const Tri& t) { return 0.5 * length(cross(t.v1 - t.v0, t.v2 - t.v0)); }
 inline double brdf_pdf_dir(const Material& m, V3 wo, V3 wi, V3 n) {
-    if (m.kind == PT_MAT_GLOSSY) {
-        double p = glossy_pdf_dir(m.roughness, wo, wi, n);
+    if (is_glossy(m.kind)) {
+        double p = glossy_pdf_dir(m.roughness, wo, wi, n, m.kind == PT_MAT_GLOSSY_GGX);
         return p > 0. ? p : 0.;
     }
     if (m.kind != PT_MAT_LAMBERT) return 0.;  // specular: a light sample has zero weight
@@ -699,6 +752,7 @@ inline double brdf_pdf_dir(const Material& m, V3 wo, V3 wi, V3 n) {
 }
 inline V3 brdf_eval(const Scene& sc, const Material& m, const Surface& s, V3 wo, V3 wi) {
     if (m.kind == PT_MAT_GLOSSY) return glossy_f(Beckmann(m.roughness), m.color, wo, wi, s.normal);
+    if (m.kind == PT_MAT_GLOSSY_GGX) return glossy_f(GGX(m.roughness), m.color, wo, wi, s.normal);
     return get_diffuse(sc, m, s) * FRAC_1_PI;
 }
 inline double light_pdf_dir(const Scene& sc, const Tri& lt, V3 from, V3 dir, double dist) {
@@ -1026,6 +1080,16 @@ double orc_beckmann_D(double roughness, const double m[3], const double n[3]) {
 }
 double orc_beckmann_G1(double roughness, const double w[3], const double m[3], const double n[3]) {
     return Beckmann(roughness).G1(v3(w[0], w[1], w[2]), v3(m[0], m[1], m[2]), v3(n[0], n[1], n[2]));
+}
+double orc_ggx_D(double roughness, const double m[3], const double n[3]) {
+    return GGX(roughness).D(v3(m[0], m[1], m[2]), v3(n[0], n[1], n[2]));
+}
+double orc_ggx_G1(double roughness, const double w[3], const double m[3], const double n[3]) {
+    return GGX(roughness).G1(v3(w[0], w[1], w[2]), v3(m[0], m[1], m[2]), v3(n[0], n[1], n[2]));
+}
+void orc_ggx_sample_normal(double roughness, const double n[3], double xi1, double xi2, double* h3) {
+    V3 h = GGX(roughness).sample_microfacet_normal(v3(n[0], n[1], n[2]), xi1, xi2);
+    h3[0] = h.x; h3[1] = h.y; h3[2] = h.z;
 }
 void orc_conductor(double cos_theta_i, double ior_i, double ior_t, double absorption, double* out3) {
     V3 one = v3(1, 1, 1);

@@ -14,10 +14,10 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpt_hip.so")
 
 PT_MISS = 0xFFFFFFFF
 PT_OK, PT_ERR_INVALID, PT_ERR_NOMEM, PT_ERR_DEVICE, PT_ERR_IO, PT_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
-PT_MAT_LAMBERT, PT_MAT_GLOSSY, PT_MAT_MIRROR, PT_MAT_TRANSPARENT = 0, 1, 2, 3
+PT_MAT_LAMBERT, PT_MAT_GLOSSY, PT_MAT_MIRROR, PT_MAT_TRANSPARENT, PT_MAT_GLOSSY_GGX = 0, 1, 2, 3, 4
 PT_BVH_EMPTY = 0x7FFFFFFF
 PT_FLAG_USE_DIFFS, PT_FLAG_NEE, PT_FLAG_DROP_NONFINITE, PT_FLAG_RUSSIAN_ROULETTE = 1, 2, 4, 8
-PT_LOAD_GLOSSY, PT_LOAD_TEXTURES, PT_LOAD_SPECULAR = 1, 2, 4
+PT_LOAD_GLOSSY, PT_LOAD_TEXTURES, PT_LOAD_SPECULAR, PT_LOAD_GGX = 1, 2, 4, 8
 PT_K_GENERATE, PT_K_EXTEND, PT_K_SHADE, PT_K_SHADOW, PT_K_ACCUMULATE, PT_K_PATH, PT_K_COUNT = 0, 1, 2, 3, 4, 5, 6
 KERNEL_NAMES = ("generate", "extend", "shade", "shadow", "accumulate", "path")
 

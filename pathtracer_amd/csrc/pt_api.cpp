@@ -336,7 +336,7 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
     if ((d->n_mats && !d->mats) || (d->n_texs && !d->texs)) { set_error("mats/texs missing"); return PT_ERR_INVALID; }
     for (uint32_t i = 0; i < d->n_mats; ++i) {
         const pt_material& m = d->mats[i];
-        if (m.kind < PT_MAT_LAMBERT || m.kind > PT_MAT_TRANSPARENT) { set_error("material %u: bad kind", i); return PT_ERR_INVALID; }
+        if (m.kind < PT_MAT_LAMBERT || m.kind > PT_MAT_GLOSSY_GGX) { set_error("material %u: bad kind", i); return PT_ERR_INVALID; }
         if (m.kind == PT_MAT_TRANSPARENT && !(m.ior > 0.f)) { set_error("material %u: transparent needs ior > 0", i); return PT_ERR_INVALID; }
         if (m.tex >= (int32_t)d->n_texs) { set_error("material %u: texture index out of range", i); return PT_ERR_INVALID; }
     }
@@ -415,7 +415,8 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
     for (uint32_t i = 0; i < d->n_mats; ++i) {
         const pt_material& m = d->mats[i];
         for (int c = 0; c < 3; ++c) { mats[i].color[c] = (double)m.color[c]; mats[i].emission[c] = (double)m.emission[c]; }
-        mats[i].width = std::fmax((double)m.roughness, 1e-5);  // microfacet.rs:125
+        mats[i].width = m.kind == PT_MAT_GLOSSY_GGX ? (double)m.roughness                 // GGX::new, microfacet.rs:197-199
+                                                    : std::fmax((double)m.roughness, 1e-5);  // Beckmann::new, microfacet.rs:125
         mats[i].kind = m.kind;
         mats[i].tex = m.tex;
         mats[i].ior = (double)m.ior;

@@ -597,23 +597,45 @@ __device__ __forceinline__ double beckmann_G1(double width, D3 w, D3 m, D3 n) { 
     if (a >= 1.6) return 1.;
     return (3.535 * a + 2.181 * a * a) / (1. + 2.276 * a + 2.577 * a * a);
 }
-__device__ D3 glossy_f(double width, D3 reflectance, D3 wo, D3 wi, D3 n) {  // microfacet.rs:64-93
+// microfacet.rs:192-243 GGX; tan2_theta = max(0, 1 - c^2) / c^2 (microfacet.rs:366-381)
+__device__ __forceinline__ double ggx_D(double alpha, D3 h, D3 n) {
+    double cos_theta = dot(h, n);
+    if (cos_theta <= 0.0) return 0.;
+    double alpha_g_sqr = alpha * alpha;
+    double c2 = cos_theta * cos_theta;
+    double tan_theta_sqr = fmax(0., 1. - c2) / c2;
+    if (isinf(tan_theta_sqr)) return 0.;
+    double alpha_tan2 = alpha_g_sqr + tan_theta_sqr;
+    return alpha_g_sqr / (PT_PI * (c2 * c2) * (alpha_tan2 * alpha_tan2));
+}
+__device__ __forceinline__ double ggx_G1(double alpha, D3 w, D3 vh) {
+    double cos_theta = dot(w, vh);
+    double cos_theta_sqr = cos_theta * cos_theta;
+    double tan_theta_sqr = (1. - cos_theta_sqr) / cos_theta_sqr;
+    return 2. / (1. + sqrt(1. + alpha * alpha * tan_theta_sqr));
+}
+__device__ __forceinline__ double facet_D(bool ggx, double width, D3 m, D3 n) {
+    return ggx ? ggx_D(width, m, n) : beckmann_D(width, m, n);
+}
+__device__ D3 glossy_f(double width, D3 reflectance, D3 wo, D3 wi, D3 n, bool ggx) {  // microfacet.rs:64-93
     D3 wh = normalize(wo + wi);
     double cos_theta_o = fabs(dot(wo, n));
     double cos_theta_i = fabs(dot(wi, n));
     if (cos_theta_i == 0. || cos_theta_o == 0.) return mk(0., 0., 0.);
     if (wh.x == 0. && wh.y == 0. && wh.z == 0.) return mk(0., 0., 0.);
     double fresnel = conductor32(dot(wo, wh));
-    double dd = beckmann_D(width, wh, n);
+    double dd = facet_D(ggx, width, wh, n);
     D3 hv = normalize(wi + wo);  // microfacet.rs:105
-    double t = beckmann_G1(width, wo, hv, n) * beckmann_G1(width, wi, hv, n);
+    double t = ggx ? ggx_G1(width, wo, hv) * ggx_G1(width, wi, hv)
+                   : beckmann_G1(width, wo, hv, n) * beckmann_G1(width, wi, hv, n);
     double g = t < 0. ? 0. : (t > 1. ? 1. : t);
     return reflectance * dd * g * mk(fresnel, fresnel, fresnel) / (4. * cos_theta_i * cos_theta_o);
 }
-__device__ __forceinline__ double glossy_pdf_dir(double width, D3 wo, D3 wi, D3 n) {
+__device__ __forceinline__ double glossy_pdf_dir(double width, D3 wo, D3 wi, D3 n, bool ggx) {
     D3 h = normalize(wo + wi);
-    return beckmann_D(width, h, n) * fabs(dot(h, n)) / (4. * dot(wo, h));
+    return facet_D(ggx, width, h, n) * fabs(dot(h, n)) / (4. * dot(wo, h));
 }
+__device__ __forceinline__ bool is_glossy(int kind) { return kind == PT_MAT_GLOSSY || kind == PT_MAT_GLOSSY_GGX; }
 
 struct Brdf {
     D3 f, wi;
@@ -664,18 +686,27 @@ __device__ __forceinline__ Brdf lambertian_sample(D3 color, D3 n, double xi1, do
     return {color * PT_FRAC_1_PI, wi, dot(n, wi) * PT_FRAC_1_PI};
 }
 // microfacet.rs:52-62 + 147-159
-__device__ Brdf glossy_sample(double width, D3 reflectance, D3 ray_dir, D3 n, double xi1, double xi2) {
+__device__ Brdf glossy_sample(double width, D3 reflectance, D3 ray_dir, D3 n, double xi1, double xi2, bool ggx) {
     D3 wo = -ray_dir;
-    double tan_theta_sqr = -width * width * log(1. - xi1);
-    double phi = 2.0 * PT_PI * xi2;
-    double cos_theta = 1. / sqrt(1. + tan_theta_sqr);
-    double sin_theta = sqrt(fmax(0., 1. - cos_theta * cos_theta));
+    double phi, cos_theta, sin_theta;
+    if (ggx) {  // microfacet.rs:203-217
+        double tan_theta_sqr = width * width * xi1 / (1. - xi1);
+        phi = 2.0 * xi2 * PT_PI;
+        double cos_theta_sqr = 1. / (1. + tan_theta_sqr);
+        cos_theta = sqrt(cos_theta_sqr);
+        sin_theta = sqrt(1. - cos_theta_sqr);
+    } else {
+        double tan_theta_sqr = -width * width * log(1. - xi1);
+        phi = 2.0 * PT_PI * xi2;
+        cos_theta = 1. / sqrt(1. + tan_theta_sqr);
+        sin_theta = sqrt(fmax(0., 1. - cos_theta * cos_theta));
+    }
     double sp, cp;
     sincos(phi, &sp, &cp);
     D3 h = normalize(rotate_to(mk(sin_theta * cp, sin_theta * sp, cos_theta), n));
     D3 wi = reflect(-wo, h);
-    double pdf = beckmann_D(width, h, n) * fabs(dot(h, n)) / (4. * dot(wo, h));
-    D3 f = glossy_f(width, reflectance, wo, wi, n);
+    double pdf = facet_D(ggx, width, h, n) * fabs(dot(h, n)) / (4. * dot(wo, h));
+    D3 f = glossy_f(width, reflectance, wo, wi, n, ggx);
     return {f, wi, pdf};
 }
 
@@ -836,8 +867,8 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
                 D3 wl = diff / dist;
                 D3 wo = -d;
                 double p_b;
-                if ((!PLAIN && m.kind == PT_MAT_GLOSSY)) {
-                    double pg = glossy_pdf_dir(m.width, wo, wl, normal);
+                if ((!PLAIN && is_glossy(m.kind))) {
+                    double pg = glossy_pdf_dir(m.width, wo, wl, normal, m.kind == PT_MAT_GLOSSY_GGX);
                     p_b = pg > 0. ? pg : 0.;
                 } else if (!PLAIN && m.kind != PT_MAT_LAMBERT) {
                     p_b = 0.;  // specular: a light sample has zero weight
@@ -848,7 +879,7 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
                 double cos_l = fabs(dot(ld3(L.normal), wl));
                 double p_l = cos_l <= 0. ? 0. : dist * dist / (sc.light_area * cos_l);
                 if (p_l > 0. && p_b > 0. && dist > 0.) {
-                    D3 f = (!PLAIN && m.kind == PT_MAT_GLOSSY) ? glossy_f(m.width, ld3(m.color), wo, wl, normal)
+                    D3 f = (!PLAIN && is_glossy(m.kind)) ? glossy_f(m.width, ld3(m.color), wo, wl, normal, m.kind == PT_MAT_GLOSSY_GGX)
                                                    : diffuse * PT_FRAC_1_PI;
                     double cosn = fabs(dot(wl, normal));
                     double wgt = p_l / (p_l + p_b);
@@ -870,12 +901,12 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
             if (!absorbed) {
                 double xi1, xi2;
                 uniform2(fr.seed, pixel, sample, bounce, STREAM_BRDF, xi1, xi2);
-                if (!PLAIN && m.kind >= PT_MAT_MIRROR) {
+                if (!PLAIN && (m.kind == PT_MAT_MIRROR || m.kind == PT_MAT_TRANSPARENT)) {
                     r.n_T = T;  // specular: radiance passes unchanged
                     r.n_d = specular_sample(m, d, normal, xi1);
                     r.n_pdf = -1.;
                 } else {
-                    Brdf bs = (!PLAIN && m.kind == PT_MAT_GLOSSY) ? glossy_sample(m.width, ld3(m.color), d, normal, xi1, xi2)
+                    Brdf bs = (!PLAIN && is_glossy(m.kind)) ? glossy_sample(m.width, ld3(m.color), d, normal, xi1, xi2, m.kind == PT_MAT_GLOSSY_GGX)
                                                       : lambertian_sample(diffuse, normal, xi1, xi2);
                     r.n_T = T * (bs.f * fabs(dot(bs.wi, normal)) / bs.pdf);  // main.rs:311
                     r.n_d = bs.wi;
@@ -1058,8 +1089,8 @@ __global__ void k_sample_brdf(Scene sc, Frame fr, uint32_t bounce, const double*
     double xi1, xi2;
     uniform2(fr.seed, pixel, fr.sample_base, bounce, STREAM_BRDF, xi1, xi2);
     Brdf bs;
-    if (m.kind >= PT_MAT_MIRROR) bs = {mk(1., 1., 1.), specular_sample(m, d, normal, xi1), -1.};  // pdf < 0: specular
-    else if (m.kind == PT_MAT_GLOSSY) bs = glossy_sample(m.width, ld3(m.color), d, normal, xi1, xi2);
+    if (m.kind == PT_MAT_MIRROR || m.kind == PT_MAT_TRANSPARENT) bs = {mk(1., 1., 1.), specular_sample(m, d, normal, xi1), -1.};  // pdf < 0: specular
+    else if (is_glossy(m.kind)) bs = glossy_sample(m.width, ld3(m.color), d, normal, xi1, xi2, m.kind == PT_MAT_GLOSSY_GGX);
     else bs = lambertian_sample(diffuse, normal, xi1, xi2);
     D3 le = m.kind != PT_MAT_LAMBERT ? mk(0., 0., 0.) : ld3(m.emission);
     f[3 * i] = bs.f.x; f[3 * i + 1] = bs.f.y; f[3 * i + 2] = bs.f.z;

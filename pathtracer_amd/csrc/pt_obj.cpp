@@ -289,7 +289,7 @@ int pt_load_obj(const char* obj_path, uint32_t flags, pt_model** out) {
             for (int c = 0; c < 3; ++c) { pm.color[c] = m.diffuse[c]; pm.emission[c] = m.ambient[c]; }
             pm.roughness = m.shininess;
             if (want_glossy && m.illum == 2) {  // obj.rs:38-40 (commented wiring): Glossy::new(Ns, _, Kd)
-                pm.kind = PT_MAT_GLOSSY;
+                pm.kind = (flags & PT_LOAD_GGX) ? PT_MAT_GLOSSY_GGX : PT_MAT_GLOSSY;
                 for (int c = 0; c < 3; ++c) pm.emission[c] = 0.f;
             } else if ((flags & PT_LOAD_SPECULAR) && (m.illum == 3 || m.illum == 4)) {
                 // IlluminationModel::from (material.rs:157-170): 3 = Mirror, 4 = Transparent

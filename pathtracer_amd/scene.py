@@ -148,11 +148,12 @@ class SceneData:
         return d
 
 
-def load_obj(obj_name: str, glossy: bool = False, textures: bool = False, specular: bool = False) -> SceneData:
+def load_obj(obj_name: str, glossy: bool = False, textures: bool = False, specular: bool = False,
+             ggx: bool = False) -> SceneData:
     """obj.rs:13-107 ``load_obj``; ``glossy`` / ``textures`` / ``specular`` enable the wiring the
     reference has commented out (obj.rs:30-53; illum 3 = Mirror, 4 = Transparent)."""
     flags = ((L.PT_LOAD_GLOSSY if glossy else 0) | (L.PT_LOAD_TEXTURES if textures else 0)
-             | (L.PT_LOAD_SPECULAR if specular else 0))
+             | (L.PT_LOAD_SPECULAR if specular else 0) | (L.PT_LOAD_GGX if ggx else 0))
     h = C.c_void_p()
     L.check(L.lib.pt_load_obj(os.fsencode(obj_name), flags, C.byref(h)))
     try:
@@ -333,11 +334,11 @@ CAMERAS = {
 
 
 def scene_data(name: str, glossy: Optional[bool] = None, textures: bool = False, models_dir: str = MODELS_DIR,
-               specular: bool = False) -> SceneData:
+               specular: bool = False, ggx: bool = False) -> SceneData:
     """Loads models/<name>.obj with the camera of SURVEY.md F6 and a black background (scene.rs:177)."""
     if glossy is None:
         glossy = name == "glossy_planes"
-    data = load_obj(os.path.join(models_dir, name + ".obj"), glossy=glossy, textures=textures, specular=specular)
+    data = load_obj(os.path.join(models_dir, name + ".obj"), glossy=glossy, textures=textures, specular=specular, ggx=ggx)
     data.camera = CAMERAS[name]
     data.background = (0.0, 0.0, 0.0)
     return data

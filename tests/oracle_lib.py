@@ -48,6 +48,12 @@ lib.orc_beckmann_D.argtypes = [C.c_double, _dp, _dp]
 lib.orc_beckmann_D.restype = C.c_double
 lib.orc_beckmann_G1.argtypes = [C.c_double, _dp, _dp, _dp]
 lib.orc_beckmann_G1.restype = C.c_double
+lib.orc_ggx_D.argtypes = [C.c_double, _dp, _dp]
+lib.orc_ggx_D.restype = C.c_double
+lib.orc_ggx_G1.argtypes = [C.c_double, _dp, _dp, _dp]
+lib.orc_ggx_G1.restype = C.c_double
+lib.orc_ggx_sample_normal.argtypes = [C.c_double, _dp, C.c_double, C.c_double, _dp]
+lib.orc_ggx_sample_normal.restype = None
 lib.orc_conductor.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, _dp]
 lib.orc_conductor.restype = None
 lib.orc_fresnel_dielectric.argtypes = [C.c_double, C.c_double]
@@ -212,3 +218,17 @@ def rotate_to(v, n):
 
 def sample_sphere(r1, r2):
     return vec3_fn(lib.orc_sample_sphere, r1, r2)
+
+
+def ggx_D(roughness, m, n):
+    return lib.orc_ggx_D(roughness, _d3(m), _d3(n))
+
+
+def ggx_G1(roughness, w, m, n):
+    return lib.orc_ggx_G1(roughness, _d3(w), _d3(m), _d3(n))
+
+
+def ggx_sample_normal(roughness, n, xi1, xi2):
+    h = (C.c_double * 3)()
+    lib.orc_ggx_sample_normal(roughness, _d3(n), xi1, xi2, h)
+    return np.array(h[:])

@@ -148,3 +148,63 @@ def test_gpu_russian_roulette_matches_oracle(gpu):
     cfg = pt.Config(dim=64, samples_pr_pixel=4, bounces=7, russian_roulette=True, seed=2)
     a, b = s2.render(cfg), o2.render(cfg)
     assert (np.abs(a - b) > 1e-9 * np.maximum(1.0, np.abs(b))).mean() < 2e-3
+
+
+# ---- GGX (microfacet.rs:192-243): the reference's second, never-instantiated distribution -------
+def test_ggx_known_answers_oracle():
+    n = np.array([0.0, 0.0, 1.0])
+    for alpha in (0.8, 0.3, 0.05):
+        # normalisation: integral of D(h) (h.n) over the hemisphere = 1
+        theta = np.linspace(0.0, np.pi / 2, 200001)[:-1]
+        vals = np.array([O.ggx_D(alpha, [np.sin(t), 0.0, np.cos(t)], n) * np.cos(t) * np.sin(t) for t in theta[::50]])
+        integral = 2 * np.pi * np.trapezoid(vals, theta[::50])
+        assert abs(integral - 1.0) < 2e-3, (alpha, integral)
+        # D at the normal = 1 / (pi alpha^2); below the horizon 0
+        assert np.isclose(O.ggx_D(alpha, n, n), 1.0 / (np.pi * alpha * alpha), rtol=1e-14)
+        assert O.ggx_D(alpha, [0.0, 0.6, -0.8], n) == 0.0
+        # G1 = 2 / (1 + sqrt(1 + alpha^2 tan^2)) with the angle between w and the half vector (as written)
+        w, h = np.array([0.6, 0.0, 0.8]), np.array([0.0, 0.0, 1.0])
+        assert np.isclose(O.ggx_G1(alpha, w, h, n), 2 / (1 + np.sqrt(1 + alpha * alpha * (0.36 / 0.64))), rtol=1e-14)
+        # sampling inverts the CDF: xi1 -> tan^2 = alpha^2 xi1 / (1 - xi1); xi1 = 0 is the normal itself
+        assert np.allclose(O.ggx_sample_normal(alpha, n, 0.0, 0.3), n)
+        h = O.ggx_sample_normal(alpha, n, 0.5, 0.0)
+        assert np.isclose((1 - h[2] ** 2) / h[2] ** 2, alpha * alpha, rtol=1e-12)
+    # the sampled half vectors follow D(h)(h.n): mean of cos(theta_h) against numerical quadrature
+    alpha = 0.4
+    rng = np.random.default_rng(0)
+    cosines = [O.ggx_sample_normal(alpha, n, u, v)[2] for u, v in rng.random((20000, 2))]
+    theta = np.linspace(0.0, np.pi / 2, 20001)[:-1]
+    dens = np.array([O.ggx_D(alpha, [np.sin(t), 0.0, np.cos(t)], n) * np.cos(t) * np.sin(t) * 2 * np.pi for t in theta])
+    expect = np.trapezoid(dens * np.cos(theta), theta) / np.trapezoid(dens, theta)
+    assert abs(np.mean(cosines) - expect) < 4e-3
+
+
+@pytest.mark.gpu
+def test_gpu_ggx_matches_oracle(gpu):
+    from test_gpu_parity import bits
+    data = pt.scene_data("glossy_planes", ggx=True)
+    assert (data.mats["kind"] == pt.PT_MAT_GLOSSY_GGX).sum() >= 7
+    scene, oracle = pt.Scene(data, gpu), O.OracleScene(data)
+    cfg = pt.Config(dim=96, seed=5)
+    rays = oracle.generate_rays(cfg, 0)
+    tri, t = oracle.trace_closest(rays)
+    hit = tri != pt.PT_MISS
+    pixel = np.arange(rays.shape[0], dtype=np.uint32)[hit]
+    g = scene.sample_brdf(rays[hit], tri[hit], t[hit], pixel, cfg, 0, 0)
+    r = oracle.sample_brdf(rays[hit], tri[hit], t[hit], pixel, cfg, 0, 0)
+    kinds = data.mats[data.tri_material[tri[hit]]]["kind"]
+    rough = data.mats[data.tri_material[tri[hit]]]["roughness"]
+    m = (kinds == pt.PT_MAT_GLOSSY_GGX) & (rough >= 0.005)
+    assert m.sum() > 1000
+    # no acos/tan/exp/log in GGX: only sin/cos of phi differ by an ulp between ocml and glibc; D near
+    # the specular peak amplifies that by ~1/alpha^2
+    assert np.abs(g[1][m] - r[1][m]).max() < 1e-12                                  # wi
+    fin = np.isfinite(r[2]) & np.isfinite(r[0]).all(axis=1) & m
+    assert fin.sum() > 0.9 * m.sum()
+    assert (np.abs(g[2][fin] - r[2][fin]) <= 1e-7 * np.abs(r[2][fin])).all()      # pdf
+    assert (np.abs(g[0][fin] - r[0][fin]) <= 1e-7 * np.abs(r[0][fin]) + 1e-300).all()  # f
+    for nee in (False, True):
+        c = pt.Config(dim=64, samples_pr_pixel=4, seed=4, nee=nee, drop_nonfinite=True)
+        img, ref = scene.render(c), oracle.render(c)
+        assert np.isfinite(img).all() and ref.mean() > 1e-3
+        assert (np.abs(img - ref) > 1e-6 * np.maximum(1.0, np.abs(ref))).mean() < 1e-2
