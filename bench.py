@@ -47,9 +47,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal knobs for a 1-GPU box (never set by the driver): all ranks on one device, gloo
+    # instead of RCCL (RCCL refuses two ranks on one GPU).  The measured configuration is nccl.
+    backend = os.environ.get("PT_BENCH_BACKEND", "nccl")
+    if "PT_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["PT_BENCH_DEVICE"])
     if world > 1:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     n_gpus = world
     if args.gpus != n_gpus and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run for N>1",
@@ -89,18 +97,23 @@ def main():
     for i in range(args.steps):
         step(args.warmup + i)
     if world > 1:
-        dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI: the job's one exchange
+        if backend == "nccl":
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI: the job's one exchange
+        else:
+            host = accum.cpu()
+            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+            accum.copy_(host)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     st = scene.stats()
     scene.set_profiling(0)
 
     samples_per_rank = npix * args.spp * args.steps
-    rays_t = torch.tensor([float(st["rays"])], dtype=torch.float64, device=dev)
+    rays_t = torch.tensor([float(st["rays"])], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(rays_t, op=dist.ReduceOp.SUM)
     total_rays = float(rays_t.item())
