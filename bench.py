@@ -29,8 +29,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--spp", type=int, default=8, help="frames per step")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -89,6 +89,9 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    if world > 1 and backend == "nccl":
+        # first use of a collective builds channels and loads its kernel: not part of a step
+        dist.reduce(torch.zeros_like(accum), dst=0, op=dist.ReduceOp.SUM)
     fence()
     scene.reset_stats()
     scene.set_profiling(1)  # HIP events around every kernel launch of the timed region

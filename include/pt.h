@@ -209,8 +209,8 @@ int pt_texture_lookup(pt_scene* scene, uint32_t tex, const double* uv /*[n][2]*/
  * (f64, the `pixels[i] += next[i]` of main.rs:434-436, frames added in index order).
  * pt_render: accum is a host buffer of width*height*3 doubles.
  * pt_render_device: accum is a device buffer on the scene's device; work is enqueued on `stream`
- * (a hipStream_t, NULL = default stream) and the call returns after enqueueing unless profiling
- * is on.  */
+ * (a hipStream_t, NULL = default stream) and the call returns after enqueueing (with profiling on,
+ * the event pairs are read back by pt_get_stats, not here).  */
 int pt_render(pt_scene* scene, const pt_render_params* params, double* accum_rgb);
 int pt_render_device(pt_scene* scene, const pt_render_params* params, double* accum_rgb_dev,
                      void* stream);

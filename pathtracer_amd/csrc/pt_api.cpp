@@ -269,9 +269,13 @@ struct Timer {  // optional HIP-event bracket around one kernel launch
     }
 };
 
-int collect_timers(pt_scene* s, hipStream_t st) {
+// Reads the recorded event pairs into pt_stats.  Called where the host waits anyway (pt_get_stats,
+// profiling switched off) and when many launches are pending — not per render call: a
+// synchronisation per step would put a host round trip between steps of a timed loop.
+constexpr size_t kMaxPendingTimers = 1u << 14;
+int collect_timers(pt_scene* s) {
     if (s->timed.empty()) return PT_OK;
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipDeviceSynchronize());
     for (auto& t : s->timed) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
@@ -529,8 +533,10 @@ int pt_scene_get_bvh(const pt_scene* s, const pt_bvh_node** nodes, uint32_t* n_n
 int pt_set_profiling(pt_scene* s, int level) {
     if (!s || level < 0 || level > 2) { set_error("bad argument"); return PT_ERR_INVALID; }
     std::lock_guard<std::mutex> lk(s->mu);
+    DeviceGuard guard(s->device);
+    int rc = collect_timers(s);  // launches timed so far count, whatever the level becomes
     s->profiling = level;
-    return PT_OK;
+    return rc;
 }
 
 int pt_reset_stats(pt_scene* s) {
@@ -539,6 +545,8 @@ int pt_reset_stats(pt_scene* s) {
     DeviceGuard guard(s->device);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemset(s->d_ctr.p, 0, sizeof(ptd::Counters)));
+    int rc = collect_timers(s);  // returns the pending events to the pool
+    if (rc != PT_OK) return rc;
     std::memset(&s->stats, 0, sizeof s->stats);
     return PT_OK;
 }
@@ -548,6 +556,8 @@ int pt_get_stats(pt_scene* s, pt_stats* out) {
     std::lock_guard<std::mutex> lk(s->mu);
     DeviceGuard guard(s->device);
     HIP_TRY(hipDeviceSynchronize());
+    int rc = collect_timers(s);
+    if (rc != PT_OK) return rc;
     ptd::Counters c;
     HIP_TRY(hipMemcpy(&c, s->d_ctr.p, sizeof c, hipMemcpyDeviceToHost));
     s->stats.rays = c.rays;
@@ -700,7 +710,7 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
         HIP_TRY(hipGetLastError());
     }
     s->stats.samples += (uint64_t)npix * P->sample_count;
-    if (s->profiling >= 1) return collect_timers(s, st);
+    if (s->timed.size() >= kMaxPendingTimers) return collect_timers(s);
     return PT_OK;
 }
 
@@ -760,7 +770,7 @@ int pt_trace_closest(pt_scene* s, const pt_ray* rays, size_t n, uint32_t* tri_id
         HIP_TRY(hipMemcpy(t + c0, hits.t, (size_t)m * sizeof(double), hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(tri_id + c0, hits.tri, (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToHost));
     }
-    if (s->profiling >= 1) return collect_timers(s, nullptr);
+    if (s->timed.size() >= kMaxPendingTimers) return collect_timers(s);
     return PT_OK;
 }
 
