@@ -25,6 +25,7 @@
 extern "C" {
 #endif
 
+#define PT_PRIM_BASE 0xF0000000u /* tri_id of a hit on analytic primitive k is PT_PRIM_BASE + k */
 #define PT_MISS 0xFFFFFFFFu /* tri_id value for "no hit" (Option::None of scene.rs:61) */
 
 typedef enum pt_status {
@@ -95,6 +96,24 @@ typedef struct pt_bvh_node {
 /* Flat scene = what scene.rs:13-18 + obj.rs:13-107 + triangle_mesh.rs:12-57 hold, with the
  * per-model TriMesh/Geometry boxes flattened into one triangle list in OBJ model/face order
  * (there is no instancing in the reference). */
+/* Analytic primitives of geometry/mod.rs:20-158 (no reference scene holds one).
+ *   SPHERE: Sphere::intersect, mod.rs:51-72: p = o - c, b = d.p, c = p.p - r^2, t = -b -/+ sqrt(b^2 - c)
+ *           (the direction is taken as unit length), the nearer root with t_min < t < t_max;
+ *           normal = (hit - c).normalize().
+ *   PLANE : Plane::intersect, mod.rs:31-48: |n.d| >= 1e-6, t = (origin - o).n / (n.d), accepted for
+ *           t_min <= t <= t_max; normal = n as given.
+ * Untextured materials only.  An emissive sphere is also a light of the NEE extension (uniform
+ * point on the sphere as lights.rs:7-15,70-78 draws it, proper solid-angle pdf + MIS instead of the
+ * constant 1/(4 pi) of lights.rs:76); an emissive plane is refused (infinite area). */
+enum { PT_PRIM_SPHERE = 0, PT_PRIM_PLANE = 1 };
+typedef struct pt_primitive {
+    int32_t kind;      /* PT_PRIM_* */
+    uint32_t material; /* index into mats */
+    double p[3];       /* sphere centre / plane origin */
+    double n[3];       /* plane normal (unused for spheres) */
+    double radius;     /* sphere */
+} pt_primitive;
+
 typedef struct pt_scene_desc {
     const float* verts;           /* [n_verts][3] positions, f32 as tobj delivers them (obj.rs:22-27) */
     uint32_t n_verts;
@@ -114,7 +133,10 @@ typedef struct pt_scene_desc {
     const pt_bvh_node* bvh_nodes;
     uint32_t n_bvh_nodes;
     const uint32_t* bvh_tri_order; /* [n_tris] triangle ids in leaf order */
+    const pt_primitive* prims;     /* analytic primitives, tested against every ray (at most PT_MAX_PRIMS) */
+    uint32_t n_prims;
 } pt_scene_desc;
+#define PT_MAX_PRIMS 256u
 
 /* geometry/ray.rs:5-14 without the differential rays (those are rebuilt from the pixel, §DESIGN) */
 typedef struct pt_ray {
@@ -182,7 +204,7 @@ int pt_bvh_build(const float* verts, uint32_t n_verts, const uint32_t* tris, uin
                  uint32_t* n_nodes_out, uint32_t* order_out, uint32_t* max_depth_out);
 
 /* ---- scene.rs:61 Scene::trace_closest on an explicit ray set (the extend kernel alone).
- * tri_id[i] = global triangle id (desc order) or PT_MISS; t[i] = hit distance (unchanged t_max on a miss).
+ * tri_id[i] = global triangle id (desc order), PT_PRIM_BASE + k for primitive k, or PT_MISS; t[i] = hit distance (unchanged t_max on a miss).
  * Tie rule for bit-identical t: lowest triangle id. */
 int pt_trace_closest(pt_scene* scene, const pt_ray* rays, size_t n, uint32_t* tri_id, double* t);
 

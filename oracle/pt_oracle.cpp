@@ -472,8 +472,16 @@ struct BNode {  // oracle's own BVH (median split over centroids); f64 boxes, no
     uint32_t first, count;
 };
 
+struct Prim {  // geometry/mod.rs:20-29
+    int kind;
+    uint32_t mat;
+    V3 p, n;
+    double radius;
+};
+
 struct Scene {
     std::vector<Tri> tris;
+    std::vector<Prim> prims;
     std::vector<Material> mats;
     std::vector<MipMap> texs;
     pt_camera cam;
@@ -537,13 +545,47 @@ inline Surface tri_surface(const Tri& tr, const Ray& ray, double t, double v, do
 // scene.rs:61-63 trace_closest by brute force over all triangles in id order.  Candidates are
 // offered in increasing id; the reference accepts t <= t_max (triangle_mesh.rs:113), the
 // build-defined tie rule keeps the lowest id, hence the strict `<` after the first hit.
-inline Hit closest_brute(const Scene& sc, V3 o, V3 d, double t_min, double t_max) {
+// geometry/mod.rs:31-72: Plane::intersect / Sphere::intersect, the accept/reject part
+inline bool prim_test(const Prim& pr, V3 o, V3 d, double t_min, double t_max, double& t_out) {
+    if (pr.kind == PT_PRIM_PLANE) {
+        double denom = dot(pr.n, d);
+        if (std::fabs(denom) < 1e-6) return false;
+        double t = dot(pr.p - o, pr.n) / denom;
+        if (t > t_max || t < t_min) return false;
+        t_out = t;
+        return true;
+    }
+    V3 p = o - pr.p;
+    double b = dot(d, p);
+    double c = dot(p, p) - pr.radius * pr.radius;
+    if (b * b < 0.) return false;
+    double dd = std::sqrt(b * b - c);  // NaN when the ray misses: both comparisons below fail
+    double t1 = (-b - dd);
+    double t2 = (-b + dd);
+    if (t1 > t_min && t1 < t_max) { t_out = t1; return true; }
+    if (t2 > t_min && t2 < t_max) { t_out = t2; return true; }
+    return false;
+}
+// the analytic primitives are tested first (ids PT_PRIM_BASE + k, above every triangle id, so a
+// triangle at a bit-identical t wins the build's lowest-id tie rule)
+inline Hit closest_prims(const Scene& sc, V3 o, V3 d, double t_min, double t_max) {
     Hit best;
     best.t = t_max;
+    for (uint32_t k = 0; k < (uint32_t)sc.prims.size(); ++k) {
+        double t;
+        if (!prim_test(sc.prims[k], o, d, t_min, best.t, t)) continue;
+        if (best.tri != PT_MISS && !(t < best.t)) continue;
+        best.tri = PT_PRIM_BASE + k; best.t = t;
+    }
+    return best;
+}
+
+inline Hit closest_brute(const Scene& sc, V3 o, V3 d, double t_min, double t_max) {
+    Hit best = closest_prims(sc, o, d, t_min, t_max);
     for (uint32_t i = 0; i < (uint32_t)sc.tris.size(); ++i) {
         double t, v, w;
         if (!tri_test(sc.tris[i], o, d, t_min, best.t, t, v, w)) continue;
-        if (best.tri != PT_MISS && !(t < best.t)) continue;
+        if (best.tri != PT_MISS && !(t < best.t || (t == best.t && i < best.tri))) continue;
         best.tri = i; best.t = t; best.v = v; best.w = w;
     }
     return best;
@@ -625,8 +667,7 @@ inline bool slab(const BNode& n, V3 o, V3 inv, double t_min, double t_max) {
 }
 
 inline Hit closest_bvh(const Scene& sc, V3 o, V3 d, double t_min, double t_max) {
-    Hit best;
-    best.t = t_max;
+    Hit best = closest_prims(sc, o, d, t_min, t_max);
     if (sc.nodes.empty()) return best;
     V3 inv = v3(1. / d.x, 1. / d.y, 1. / d.z);
     int stack[128];
@@ -762,6 +803,19 @@ inline double light_pdf_dir(const Scene& sc, const Tri& lt, V3 from, V3 dir, dou
     (void)from;
     return dist * dist / (sc.light_cdf.back() * cos_l);
 }
+// an emissive sphere emits from its outside only (lights.rs:47-49 rejects back-facing samples)
+inline double sphere_light_pdf_dir(const Scene& sc, V3 normal_at_hit, V3 dir, double dist) {
+    double cos_l = dot(normal_at_hit, -dir);
+    if (cos_l <= 0.) return 0.;
+    return dist * dist / (sc.light_cdf.back() * cos_l);
+}
+// the hit point of an analytic primitive: Surface::new(position, normal) (mod.rs:46,71-72)
+inline Surface prim_surface(const Prim& pr, const Ray& ray, double t) {
+    Surface s;
+    s.position = ray.origin + ray.direction * t;
+    s.normal = pr.kind == PT_PRIM_PLANE ? pr.n : normalize(s.position - pr.p);
+    return s;
+}
 
 // main.rs:283-318 render()
 inline V3 render(const Scene& sc, double x, double y, double pdx, double pdy, uint32_t pixel, uint64_t sample,
@@ -781,15 +835,19 @@ inline V3 render(const Scene& sc, double x, double y, double pdx, double pdy, ui
             color_result = color_result + accumulated_pdf * sc.background;
             return color_result;
         }
-        const Tri& tr = sc.tris[h.tri];
-        const Material& m = sc.mats[tr.mat];
+        const bool on_prim = h.tri >= PT_PRIM_BASE;
+        static const Tri no_tri{};
+        const Tri& tr = on_prim ? no_tri : sc.tris[h.tri];
+        const Material& m = sc.mats[on_prim ? sc.prims[h.tri - PT_PRIM_BASE].mat : tr.mat];
         Ray hit_ray = trace_ray;
         hit_ray.t_max = h.t;
-        Surface surface = tri_surface(tr, hit_ray, h.t, h.v, h.w, use_diffs);
+        Surface surface = on_prim ? prim_surface(sc.prims[h.tri - PT_PRIM_BASE], hit_ray, h.t)
+                                  : tri_surface(tr, hit_ray, h.t, h.v, h.w, use_diffs);
 
         V3 le = emission_of(m);
         if (nee && bounce > 0 && (le.x != 0. || le.y != 0. || le.z != 0.)) {
-            double p_l = light_pdf_dir(sc, tr, trace_ray.origin, trace_ray.direction, h.t);
+            double p_l = on_prim ? sphere_light_pdf_dir(sc, surface.normal, trace_ray.direction, h.t)
+                                 : light_pdf_dir(sc, tr, trace_ray.origin, trace_ray.direction, h.t);
             // prev_pdf < 0: the ray came from a specular vertex, which no light sample can reach
             double wgt = prev_pdf > 0. ? prev_pdf / (prev_pdf + p_l) : (prev_pdf < 0. ? 1. : 0.);
             color_result = color_result + accumulated_pdf * le * wgt;
@@ -808,16 +866,31 @@ inline V3 render(const Scene& sc, double x, double y, double pdx, double pdy, ui
             double u1 = (target - lo) / (sc.light_cdf[li] - lo);
             if (!(u1 >= 0.)) u1 = 0.;
             if (u1 > 1.) u1 = 1.;
-            const Tri& lt = sc.tris[sc.lights[li]];
-            double su = std::sqrt(u1);
-            double b0 = 1. - su, b1 = r[1] * su;
-            V3 lp = lt.v0 * b0 + lt.v1 * b1 + lt.v2 * (1. - b0 - b1);
+            const bool sphere_light = sc.lights[li] >= PT_PRIM_BASE;
+            const Tri& lt = sphere_light ? no_tri : sc.tris[sc.lights[li]];
+            V3 lp, sphere_n = v3(0, 0, 0);
+            uint32_t light_mat;
+            if (sphere_light) {  // lights.rs:7-15 sample_sphere + :70-78 Sphere::sample_surface
+                const Prim& sp = sc.prims[sc.lights[li] - PT_PRIM_BASE];
+                double z = 1. - 2. * u1;
+                double rr = std::sqrt(std::fmax(0., 1. - z * z));
+                double phi = 2. * PI * r[1];
+                sphere_n = v3(rr * std::cos(phi), rr * std::sin(phi), z);
+                lp = sphere_n * sp.radius + sp.p;
+                light_mat = sp.mat;
+            } else {
+                double su = std::sqrt(u1);
+                double b0 = 1. - su, b1 = r[1] * su;
+                lp = lt.v0 * b0 + lt.v1 * b1 + lt.v2 * (1. - b0 - b1);
+                light_mat = lt.mat;
+            }
             V3 diff = lp - surface.position;
             double dist = length(diff);
             V3 wl = diff / dist;
             V3 wo = -trace_ray.direction;
             double p_b = brdf_pdf_dir(m, wo, wl, surface.normal);
-            double p_l = light_pdf_dir(sc, lt, surface.position, wl, dist);
+            double p_l = sphere_light ? sphere_light_pdf_dir(sc, sphere_n, wl, dist)
+                                      : light_pdf_dir(sc, lt, surface.position, wl, dist);
             if (p_l > 0. && p_b > 0. && dist > 0.) {
                 Ray shadow(surface.position, wl);
                 shadow.t_max = dist * (1. - 1e-9);
@@ -826,7 +899,7 @@ inline V3 render(const Scene& sc, double x, double y, double pdx, double pdy, ui
                 if (visible) {
                     V3 f = brdf_eval(sc, m, surface, wo, wl);
                     double cosn = std::fabs(dot(wl, surface.normal));
-                    V3 lle = emission_of(sc.mats[lt.mat]);
+                    V3 lle = emission_of(sc.mats[light_mat]);
                     double wgt = p_l / (p_l + p_b);
                     color_result = color_result + accumulated_pdf * f * lle * (cosn * wgt / p_l);
                 }
@@ -918,6 +991,16 @@ int orc_scene_create(const pt_scene_desc* d, orc_scene** out) {
         t.mat = d->tri_material ? d->tri_material[i] : 0;
         if (t.mat >= sc.mats.size()) { delete s; return PT_ERR_INVALID; }
     }
+    if (d->n_prims > PT_MAX_PRIMS) { delete s; return PT_ERR_UNSUPPORTED; }
+    for (uint32_t k = 0; k < d->n_prims; ++k) {
+        const pt_primitive& q = d->prims[k];
+        if ((q.kind != PT_PRIM_SPHERE && q.kind != PT_PRIM_PLANE) || q.material >= sc.mats.size()) { delete s; return PT_ERR_INVALID; }
+        Prim pr;
+        pr.kind = q.kind; pr.mat = q.material;
+        pr.p = v3(q.p[0], q.p[1], q.p[2]); pr.n = v3(q.n[0], q.n[1], q.n[2]);
+        pr.radius = q.radius;
+        sc.prims.push_back(pr);
+    }
     Builder(sc).run();
     double acc = 0.;
     for (uint32_t i = 0; i < d->n_tris; ++i) {
@@ -926,6 +1009,13 @@ int orc_scene_create(const pt_scene_desc* d, orc_scene** out) {
             double a = tri_area(sc.tris[i]);
             if (a > 0.) { acc += a; sc.lights.push_back(i); sc.light_cdf.push_back(acc); }
         }
+    }
+    for (uint32_t k = 0; k < d->n_prims; ++k) {  // emissive spheres after the triangles
+        V3 le = emission_of(sc.mats[sc.prims[k].mat]);
+        if (le.x == 0. && le.y == 0. && le.z == 0.) continue;
+        if (sc.prims[k].kind != PT_PRIM_SPHERE) { delete s; return PT_ERR_UNSUPPORTED; }  // infinite area
+        double a = 4. * PI * sc.prims[k].radius * sc.prims[k].radius;
+        if (a > 0.) { acc += a; sc.lights.push_back(PT_PRIM_BASE + k); sc.light_cdf.push_back(acc); }
     }
     *out = s;
     return PT_OK;
@@ -1003,8 +1093,10 @@ int orc_sample_brdf(const orc_scene* s, const pt_ray* rays, const uint32_t* tri_
     const Scene& sc = s->sc;
     bool use_diffs = (flags & PT_FLAG_USE_DIFFS) != 0;
     for (size_t i = 0; i < n; ++i) {
-        if (tri_id[i] >= sc.tris.size()) return PT_ERR_INVALID;
-        const Tri& tr = sc.tris[tri_id[i]];
+        const bool on_prim = tri_id[i] >= PT_PRIM_BASE;
+        if (on_prim ? tri_id[i] - PT_PRIM_BASE >= sc.prims.size() : tri_id[i] >= sc.tris.size()) return PT_ERR_INVALID;
+        static const Tri no_tri{};
+        const Tri& tr = on_prim ? no_tri : sc.tris[tri_id[i]];
         Ray r(v3(rays[i].o[0], rays[i].o[1], rays[i].o[2]), v3(rays[i].d[0], rays[i].d[1], rays[i].d[2]));
         if (bounce == 0 && use_diffs) {
             // primary rays carry differentials: rebuild them from the pixel (scene.rs:47-54)
@@ -1017,10 +1109,10 @@ int orc_sample_brdf(const orc_scene* s, const pt_ray* rays, const uint32_t* tri_
         }
         // recompute barycentrics with the reference arithmetic
         double tt, v, w;
-        if (!tri_test(tr, r.origin, r.direction, -INFINITY, INFINITY, tt, v, w)) { v = 0; w = 0; }
+        if (on_prim || !tri_test(tr, r.origin, r.direction, -INFINITY, INFINITY, tt, v, w)) { v = 0; w = 0; }
         r.t_max = t[i];
-        Surface surf = tri_surface(tr, r, t[i], v, w, use_diffs);
-        const Material& m = sc.mats[tr.mat];
+        Surface surf = on_prim ? prim_surface(sc.prims[tri_id[i] - PT_PRIM_BASE], r, t[i]) : tri_surface(tr, r, t[i], v, w, use_diffs);
+        const Material& m = sc.mats[on_prim ? sc.prims[tri_id[i] - PT_PRIM_BASE].mat : tr.mat];
         double xi[2];
         uniform2(seed, pixel[i], sample, bounce, STREAM_BRDF, xi);
         BrdfSample bs = sample_brdf(sc, m, surf, r.direction, xi[0], xi[1]);

@@ -13,6 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpt_hip.so")
 
 PT_MISS = 0xFFFFFFFF
+PT_PRIM_BASE = 0xF0000000
+PT_PRIM_SPHERE, PT_PRIM_PLANE = 0, 1
 PT_OK, PT_ERR_INVALID, PT_ERR_NOMEM, PT_ERR_DEVICE, PT_ERR_IO, PT_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 PT_MAT_LAMBERT, PT_MAT_GLOSSY, PT_MAT_MIRROR, PT_MAT_TRANSPARENT, PT_MAT_GLOSSY_GGX = 0, 1, 2, 3, 4
 PT_BVH_EMPTY = 0x7FFFFFFF
@@ -40,6 +42,11 @@ class pt_bvh_node(C.Structure):
     _fields_ = [("bounds", C.c_float * 12), ("child", C.c_int32 * 2), ("pad", C.c_uint32 * 2)]
 
 
+class pt_primitive(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("material", C.c_uint32), ("p", C.c_double * 3), ("n", C.c_double * 3),
+                ("radius", C.c_double)]
+
+
 class pt_scene_desc(C.Structure):
     _fields_ = [("verts", C.POINTER(C.c_float)), ("n_verts", C.c_uint32),
                 ("tris", C.POINTER(C.c_uint32)), ("n_tris", C.c_uint32),
@@ -49,7 +56,8 @@ class pt_scene_desc(C.Structure):
                 ("texs", C.POINTER(pt_texture)), ("n_texs", C.c_uint32),
                 ("camera", pt_camera), ("background", C.c_double * 3),
                 ("bvh_nodes", C.POINTER(pt_bvh_node)), ("n_bvh_nodes", C.c_uint32),
-                ("bvh_tri_order", C.POINTER(C.c_uint32))]
+                ("bvh_tri_order", C.POINTER(C.c_uint32)),
+                ("prims", C.POINTER(pt_primitive)), ("n_prims", C.c_uint32)]
 
 
 class pt_ray(C.Structure):

@@ -149,7 +149,7 @@ struct pt_scene {
     std::vector<uint32_t> order;
     uint32_t depth = 0;
     ptd::Scene dev{};
-    DevBuf d_nodes, d_tris, d_uvs, d_leaf_of, d_mats, d_texs, d_lights, d_ctr;
+    DevBuf d_nodes, d_tris, d_uvs, d_leaf_of, d_mats, d_texs, d_lights, d_prims, d_ctr;
     std::vector<DevBuf*> d_texels;
     Workspace ws;
     std::mutex mu;
@@ -349,6 +349,18 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
         for (int k = 0; k < 3; ++k)
             if (d->tris[3 * i + k] >= d->n_verts) { set_error("triangle %u: vertex out of range", i); return PT_ERR_INVALID; }
     }
+    if (d->n_prims && !d->prims) { set_error("prims missing"); return PT_ERR_INVALID; }
+    if (d->n_prims > PT_MAX_PRIMS) { set_error("more than %u analytic primitives", PT_MAX_PRIMS); return PT_ERR_UNSUPPORTED; }
+    for (uint32_t k = 0; k < d->n_prims; ++k) {
+        const pt_primitive& q = d->prims[k];
+        if (q.kind != PT_PRIM_SPHERE && q.kind != PT_PRIM_PLANE) { set_error("primitive %u: bad kind", k); return PT_ERR_INVALID; }
+        if (q.material >= d->n_mats) { set_error("primitive %u: material out of range", k); return PT_ERR_INVALID; }
+        const pt_material& m = d->mats[q.material];
+        if (m.tex >= 0) { set_error("primitive %u: textured materials need triangle uvs", k); return PT_ERR_UNSUPPORTED; }
+        bool emissive = m.kind == PT_MAT_LAMBERT && (m.emission[0] != 0.f || m.emission[1] != 0.f || m.emission[2] != 0.f);
+        if (emissive && q.kind == PT_PRIM_PLANE) { set_error("primitive %u: an emissive plane has infinite area", k); return PT_ERR_UNSUPPORTED; }
+        if (q.kind == PT_PRIM_SPHERE && !(q.radius > 0.)) { set_error("primitive %u: sphere radius must be positive", k); return PT_ERR_INVALID; }
+    }
     int n_dev = 0;
     hipError_t dev_err = hipGetDeviceCount(&n_dev);
     if (dev_err != hipSuccess || n_dev <= 0) {
@@ -473,7 +485,29 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
         L.leaf_index = leaf_of[g];
         lights.push_back(L);
     }
+    // emissive spheres after the triangles (same order as the oracle's CDF)
+    std::vector<ptd::Prim> prims(d->n_prims);
+    for (uint32_t k = 0; k < d->n_prims; ++k) {
+        const pt_primitive& q = d->prims[k];
+        for (int a = 0; a < 3; ++a) { prims[k].p[a] = q.p[a]; prims[k].n[a] = q.n[a]; }
+        prims[k].radius = q.radius;
+        prims[k].kind = q.kind;
+        prims[k].mat = q.material;
+        const ptd::Material& m = mats[q.material];
+        if (q.kind != PT_PRIM_SPHERE || m.kind != PT_MAT_LAMBERT) continue;
+        if (m.emission[0] == 0. && m.emission[1] == 0. && m.emission[2] == 0.) continue;
+        acc += 4. * 3.14159265358979323846 * q.radius * q.radius;
+        ptd::Light L;
+        std::memset(&L, 0, sizeof L);
+        for (int a = 0; a < 3; ++a) { L.v0[a] = q.p[a]; L.emission[a] = m.emission[a]; }
+        L.v1[0] = q.radius;
+        L.cdf = acc;
+        L.leaf_index = PT_PRIM_BASE + k;
+        L.sphere = 1;
+        lights.push_back(L);
+    }
     if ((rc = upload(s->d_lights, lights.data(), lights.size())) != PT_OK) return rc;
+    if ((rc = upload(s->d_prims, prims.data(), prims.size())) != PT_OK) return rc;
 
     HIP_TRY(s->d_ctr.alloc(sizeof(ptd::Counters)));
     HIP_TRY(hipMemset(s->d_ctr.p, 0, sizeof(ptd::Counters)));
@@ -486,6 +520,8 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
     dv.mats = s->d_mats.as<ptd::Material>();
     dv.texs = s->d_texs.as<ptd::Texture>();
     dv.lights = s->d_lights.as<ptd::Light>();
+    dv.prims = s->d_prims.as<ptd::Prim>();
+    dv.n_prims = d->n_prims;
     dv.n_nodes = d->n_tris ? (uint32_t)s->nodes.size() : 0u;
     dv.n_tris = d->n_tris;
     dv.n_lights = (uint32_t)lights.size();

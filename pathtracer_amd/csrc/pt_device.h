@@ -37,13 +37,20 @@ struct Camera {  // scene.rs:37-43 with the per-ray invariant parts hoisted to t
     double axes1[3];     // -(axes0 x view).normalize()
 };
 
-struct Light {  // one emissive triangle (NEE)
+struct Prim {  // analytic sphere / plane (geometry/mod.rs:20-29), SURVEY §8f N4
+    double p[3], n[3];
+    double radius;
+    int32_t kind;
+    uint32_t mat;
+};
+
+struct Light {  // one emissive triangle, or (sphere != 0) an emissive sphere: v0 = centre, v1[0] = radius (NEE)
     double v0[3], v1[3], v2[3];
     double normal[3];  // unit geometric normal
     double emission[3];
     double cdf;        // cumulative area up to and including this triangle
     uint32_t leaf_index;  // index of the triangle in leaf order
-    uint32_t pad;
+    uint32_t sphere;
 };
 
 struct Scene {
@@ -54,6 +61,8 @@ struct Scene {
     const Material* mats;
     const Texture* texs;
     const Light* lights;
+    const Prim* prims;  // tested against every ray before the tree is walked; hit id PT_PRIM_BASE + k
+    uint32_t n_prims;
     uint32_t n_nodes, n_tris, n_lights, bvh_depth;
     double light_area;
     uint32_t plain;  // only untextured Lambertian materials (selects the lean shade kernel)

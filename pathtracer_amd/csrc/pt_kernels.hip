@@ -156,6 +156,39 @@ __device__ __forceinline__ bool slab(double lox, double loy, double loz, double 
 // One node step: slab-test both children, pick the next node (near child first, far child pushed)
 // or pop.  kDone marks an empty stack; it is negative like a leaf reference but decodes to a
 // triangle offset >= 2^28, which no scene has.
+// geometry/mod.rs:31-72 Plane::intersect / Sphere::intersect, the accept/reject part
+__device__ __forceinline__ bool prim_test(const Prim& pr, D3 o, D3 d, double t_min, double t_max, double& t_out) {
+    if (pr.kind == PT_PRIM_PLANE) {
+        D3 n = ld3(pr.n);
+        double denom = dot(n, d);
+        if (fabs(denom) < 1e-6) return false;
+        double t = dot(ld3(pr.p) - o, n) / denom;
+        if (t > t_max || t < t_min) return false;
+        t_out = t;
+        return true;
+    }
+    D3 p = o - ld3(pr.p);
+    double b = dot(d, p);
+    double c = dot(p, p) - pr.radius * pr.radius;
+    double dd = sqrt(b * b - c);  // NaN when the ray misses: both comparisons below fail
+    double t1 = (-b - dd);
+    double t2 = (-b + dd);
+    if (t1 > t_min && t1 < t_max) { t_out = t1; return true; }
+    if (t2 > t_min && t2 < t_max) { t_out = t2; return true; }
+    return false;
+}
+// The analytic primitives are tested before the tree is walked: a hit shortens t_max for the
+// traversal, and with ids above every triangle id a triangle at a bit-identical t wins the tie.
+__device__ __forceinline__ void prims_closest(const Scene& sc, D3 o, D3 d, double t_min, double& t_max, uint32_t& best,
+                                              uint32_t& best_id) {
+    for (uint32_t k = 0; k < sc.n_prims; ++k) {
+        double t;
+        if (!prim_test(sc.prims[k], o, d, t_min, t_max, t)) continue;
+        if (best != PT_MISS && !(t < t_max)) continue;
+        best = best_id = PT_PRIM_BASE + k;
+        t_max = t;
+    }
+}
 constexpr int kDone = (int)0x80000000;
 template <int DEPTH, bool STATS, int STRIDE = kTravBlock>
 __device__ __forceinline__ int node_step(const Scene& sc, int cur, D3 o, D3 inv, double t_min, double t_max, int* stk,
@@ -248,6 +281,10 @@ __device__ __forceinline__ void trace_range_vote(const Scene& sc, uint32_t begin
                     best = PT_MISS; best_id = PT_MISS;
                     sp = 0;
                     cur = sc.n_nodes ? 0 : kDone;
+                    if (sc.n_prims) {
+                        prims_closest(sc, o, d, t_min, t_max, best, best_id);
+                        if (ANY && best != PT_MISS) cur = kDone;
+                    }
                     busy = true;
                 }
             }
@@ -266,6 +303,10 @@ template <int DEPTH, bool ANY, bool STATS, int STRIDE = kTravBlock>
 __device__ __forceinline__ uint32_t traverse(const Scene& sc, D3 o, D3 d, double t_min, double& t_max, int* stk,
                                              uint32_t& n_nodes, uint32_t& n_tris) {
     uint32_t best = PT_MISS, best_id = PT_MISS;
+    if (sc.n_prims) {
+        prims_closest(sc, o, d, t_min, t_max, best, best_id);
+        if (ANY && best != PT_MISS) return best;
+    }
     if (sc.n_nodes == 0) return best;
     D3 inv = mk(1. / d.x, 1. / d.y, 1. / d.z);
     int sp = 0;
@@ -718,6 +759,14 @@ struct ShadePoint {
 };
 __device__ __forceinline__ void hit_geometry(const Scene& sc, uint32_t leaf, D3 o, D3 d, double t, TriV& tr,
                                              uint32_t& mat, D3& position, D3& normal) {
+    if (leaf >= PT_PRIM_BASE) {  // Surface::new(position, normal), geometry/mod.rs:46,71-72
+        const Prim& pr = sc.prims[leaf - PT_PRIM_BASE];
+        tr.v0 = tr.v1 = tr.v2 = mk(0., 0., 0.);
+        mat = pr.mat;
+        position = o + d * t;
+        normal = pr.kind == PT_PRIM_PLANE ? ld3(pr.n) : normalize(position - ld3(pr.p));
+        return;
+    }
     const float4* tp = sc.tris + (size_t)leaf * 3;
     float4 a = tp[0], b = tp[1], c = tp[2];
     tr = widen(a, b, c);
@@ -819,7 +868,8 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
     if (leaf == PT_MISS) {
         add = T * ld3(sc.background);  // main.rs:299
     } else if (!kNeedRay) {
-        uint32_t mat = (uint32_t)__float_as_int(sc.tris[(size_t)leaf * 3 + 1].w);
+        uint32_t mat = leaf >= PT_PRIM_BASE ? sc.prims[leaf - PT_PRIM_BASE].mat
+                                            : (uint32_t)__float_as_int(sc.tris[(size_t)leaf * 3 + 1].w);
         const Material& m = sc.mats[mat];
         D3 le = (!PLAIN && m.kind != PT_MAT_LAMBERT) ? mk(0., 0., 0.) : ld3(m.emission);  // microfacet.rs:33-35; specular: none
         add = T * le;  // main.rs:307
@@ -834,8 +884,10 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
         add = T * le;  // main.rs:307
         if (NEE && !FIRST && (le.x != 0. || le.y != 0. || le.z != 0.)) {
             // MIS weight of a BRDF-sampled hit on a light (balance heuristic)
-            D3 ln = normalize(cross(tr.v1 - tr.v0, tr.v2 - tr.v0));
-            double cos_l = fabs(dot(ln, d));
+            // triangles emit from both faces (main.rs:307 adds Le on any hit), spheres from outside
+            // only (lights.rs:47-49)
+            double cos_l = leaf >= PT_PRIM_BASE ? dot(normal, -d)
+                                                : fabs(dot(normalize(cross(tr.v1 - tr.v0, tr.v2 - tr.v0)), d));
             double p_l = cos_l <= 0. ? 0. : t * t / (sc.light_area * cos_l);
             double pp = in.prev_pdf[i];
             double wgt = pp > 0. ? pp / (pp + p_l) : (pp < 0. ? 1. : 0.);  // pp < 0: specular predecessor
@@ -859,9 +911,20 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
                 double u1 = (target - cdf_lo) / (L.cdf - cdf_lo);
                 if (!(u1 >= 0.)) u1 = 0.;
                 if (u1 > 1.) u1 = 1.;
-                double su = sqrt(u1);
-                double b0 = 1. - su, b1 = r1 * su;
-                D3 lp = ld3(L.v0) * b0 + ld3(L.v1) * b1 + ld3(L.v2) * (1. - b0 - b1);
+                D3 lp, sphere_n = mk(0., 0., 0.);
+                if (L.sphere) {  // lights.rs:7-15 sample_sphere + :70-78 Sphere::sample_surface
+                    double z = 1. - 2. * u1;
+                    double rr = sqrt(fmax(0., 1. - z * z));
+                    double phi = 2. * PT_PI * r1;
+                    double sp, cp;
+                    sincos(phi, &sp, &cp);
+                    sphere_n = mk(rr * cp, rr * sp, z);
+                    lp = sphere_n * L.v1[0] + ld3(L.v0);
+                } else {
+                    double su = sqrt(u1);
+                    double b0 = 1. - su, b1 = r1 * su;
+                    lp = ld3(L.v0) * b0 + ld3(L.v1) * b1 + ld3(L.v2) * (1. - b0 - b1);
+                }
                 D3 diff = lp - position;
                 double dist = length(diff);
                 D3 wl = diff / dist;
@@ -876,7 +939,7 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
                     double c = dot(normal, wl);
                     p_b = c > 0. ? c * PT_FRAC_1_PI : 0.;
                 }
-                double cos_l = fabs(dot(ld3(L.normal), wl));
+                double cos_l = L.sphere ? dot(sphere_n, -wl) : fabs(dot(ld3(L.normal), wl));
                 double p_l = cos_l <= 0. ? 0. : dist * dist / (sc.light_area * cos_l);
                 if (p_l > 0. && p_b > 0. && dist > 0.) {
                     D3 f = (!PLAIN && is_glossy(m.kind)) ? glossy_f(m.width, ld3(m.color), wo, wl, normal, m.kind == PT_MAT_GLOSSY_GGX)
@@ -1066,7 +1129,7 @@ __global__ void k_leaf_to_global(Scene sc, uint32_t* tri, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t leaf = tri[i];
-    if (leaf != PT_MISS) tri[i] = (uint32_t)__float_as_int(sc.tris[(size_t)leaf * 3].w);
+    if (leaf < PT_PRIM_BASE) tri[i] = (uint32_t)__float_as_int(sc.tris[(size_t)leaf * 3].w);  // primitives keep PT_PRIM_BASE + k
 }
 
 __global__ void k_sample_brdf(Scene sc, Frame fr, uint32_t bounce, const double* __restrict__ rays,
@@ -1077,7 +1140,7 @@ __global__ void k_sample_brdf(Scene sc, Frame fr, uint32_t bounce, const double*
     if (i >= n) return;
     const double* r = rays + (size_t)i * 8;
     D3 o = mk(r[0], r[1], r[2]), d = mk(r[3], r[4], r[5]);
-    uint32_t leaf = sc.leaf_of[tri_global[i]];
+    uint32_t leaf = tri_global[i] >= PT_PRIM_BASE ? tri_global[i] : sc.leaf_of[tri_global[i]];
     TriV tr;
     uint32_t mat;
     D3 position, normal;

@@ -26,6 +26,8 @@ NODE_DTYPE = np.dtype([("bounds", "<f4", 12), ("child", "<i4", 2), ("pad", "<u4"
 MATERIAL_DTYPE = np.dtype([("color", "<f4", 3), ("emission", "<f4", 3), ("roughness", "<f4"),
                            ("kind", "<i4"), ("tex", "<i4"), ("ior", "<f4")])
 assert MATERIAL_DTYPE.itemsize == C.sizeof(L.pt_material)
+PRIM_DTYPE = np.dtype([("kind", "<i4"), ("material", "<u4"), ("p", "<f8", 3), ("n", "<f8", 3), ("radius", "<f8")])
+assert PRIM_DTYPE.itemsize == C.sizeof(L.pt_primitive)
 
 
 def _ptr(a: np.ndarray, ctype):
@@ -105,7 +107,7 @@ class SceneData:
     """
 
     def __init__(self, verts, tris, tri_material, mats, tri_uvs=None, textures=(), camera: Camera = None,
-                 background=(0.0, 0.0, 0.0), model_names=(), model_first_tri=()):
+                 background=(0.0, 0.0, 0.0), model_names=(), model_first_tri=(), prims=None):
         self.verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
         self.tris = np.ascontiguousarray(tris, dtype=np.uint32).reshape(-1, 3)
         self.tri_material = np.ascontiguousarray(tri_material, dtype=np.uint32).reshape(-1)
@@ -118,6 +120,8 @@ class SceneData:
         self.model_first_tri = list(model_first_tri)
         self.bvh_nodes = None
         self.bvh_tri_order = None
+        # analytic spheres / planes (geometry/mod.rs:20-29), PRIM_DTYPE records; hit ids PT_PRIM_BASE + k
+        self.prims = None if prims is None else np.ascontiguousarray(prims, dtype=PRIM_DTYPE).reshape(-1)
 
     @property
     def n_tris(self) -> int:
@@ -145,6 +149,9 @@ class SceneData:
             d.bvh_nodes = C.cast(self.bvh_nodes.ctypes.data, C.POINTER(L.pt_bvh_node))
             d.n_bvh_nodes = self.bvh_nodes.shape[0]
             d.bvh_tri_order = _ptr(self.bvh_tri_order, C.c_uint32)
+        if self.prims is not None and len(self.prims):
+            d.prims = C.cast(self.prims.ctypes.data, C.POINTER(L.pt_primitive))
+            d.n_prims = self.prims.shape[0]
         return d
 
 
