@@ -382,7 +382,11 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
         s->nodes.assign(d->bvh_nodes, d->bvh_nodes + d->n_bvh_nodes);
         s->order.assign(d->bvh_tri_order, d->bvh_tri_order + d->n_tris);
     } else {
-        int rc = pth::bvh_build(d->verts, d->n_verts, d->tris, d->n_tris, 4, s->nodes, s->order, s->depth);
+        // leaves of at most 2 triangles (a quad): measured against 1/3/4/8 on both bench scenes
+        // (CornellBox 13.3/13.6/11.6/11.5, 10 M triangles 3.03/3.42/3.16/2.84 Gsamples/s; 2: 13.6/3.43)
+        uint32_t max_leaf = 2;
+        if (const char* e = getenv("PT_BVH_LEAF")) max_leaf = (uint32_t)atoi(e);
+        int rc = pth::bvh_build(d->verts, d->n_verts, d->tris, d->n_tris, max_leaf, s->nodes, s->order, s->depth);
         if (rc != PT_OK) { set_error("bvh build failed (non-finite vertex?)"); return rc; }
     }
     {
