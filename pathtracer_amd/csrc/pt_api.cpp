@@ -77,9 +77,11 @@ struct Carver {  // carves 256-byte aligned arrays out of one allocation
 };
 
 constexpr uint32_t kMaxBounces = 61;
-// counters[]: kSegs segment counters per bounce for the path queue, then the same for the shadow queue
+// counters[]: kSegs segment counters per bounce for the path queue, the same for the shadow queue,
+// then the work cursors of the persistent extend and shadow launches (one set per bounce each)
 constexpr uint32_t kCounterSets = kMaxBounces + 3;
-constexpr uint32_t kCounterWords = 2 * kCounterSets * ptd::kSegs;
+constexpr uint32_t kSetWords = ptd::kSegs * ptd::kCtrStride;  // one set: kSegs counters, a 128-byte line each
+constexpr uint32_t kCounterWords = 4 * kCounterSets * kSetWords;
 
 // One batch of frames is traced as one or two "lanes" (sample sub-ranges), each with its own
 // queues, hit records and counters.  Two lanes run on two streams, so that one lane's kernels fill
@@ -158,6 +160,7 @@ struct pt_scene {
     std::vector<TimedLaunch> timed;
     std::vector<hipEvent_t> event_pool;
     int pipeline = 0;               // 0: one lane; 1: two lanes on two streams (see Lane)
+    int persistent = 1;             // vote-scheduled launches claim their ranges from work cursors
     hipStream_t side = nullptr;     // the second lane's stream
     std::vector<hipEvent_t> sync;   // cross-stream ordering events (no timing)
     ~pt_scene() {
@@ -531,6 +534,12 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
     dv.n_lights = (uint32_t)lights.size();
     dv.bvh_depth = s->depth;
     resolve_scheduling(dv);
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+        dv.n_cu = (uint32_t)prop.multiProcessorCount;
+    }
+    if (const char* e = getenv("PT_PERSISTENT")) s->persistent = atoi(e) != 0;
     s->pipeline = dv.bvh_depth > 8;
     if (const char* e = getenv("PT_PIPELINE")) s->pipeline = atoi(e) != 0;  // tuning / tests, like the above
     dv.plain = 1;
@@ -656,8 +665,9 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
     };
     // one bounce of one lane, split in its two phases
     auto run_extend = [&](LaneRun& r, uint32_t bounce) {
-        ptd::Live live = bounce == 0 ? ptd::Live{nullptr, 0, r.n_max}
-                                     : ptd::Live{r.ln->counters + bounce * ptd::kSegs, r.seg, r.cap};
+        uint32_t* cursors = s->persistent ? r.ln->counters + (2 * kCounterSets + bounce) * kSetWords : nullptr;
+        ptd::Live live = bounce == 0 ? ptd::Live{nullptr, 0, r.n_max, nullptr}
+                                     : ptd::Live{r.ln->counters + bounce * kSetWords, r.seg, r.cap, cursors};
         Timer t(s, r.st, PT_K_EXTEND);
         // bounce 0 runs over the dense slot range; later bounces over the segmented queue
         if (bounce == 0) ptd::launch_extend_primary(s->dev, r.fr, r.ln->hits, ctr, stats, r.st);
@@ -665,11 +675,11 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
     };
     auto run_shade = [&](LaneRun& r, uint32_t bounce, bool fused) {
         uint32_t* path_cnt = r.ln->counters;
-        uint32_t* shad_cnt = r.ln->counters + kCounterSets * ptd::kSegs;
-        ptd::Live live = bounce == 0 ? ptd::Live{nullptr, 0, r.n_max}
-                                     : ptd::Live{path_cnt + bounce * ptd::kSegs, r.seg, r.cap};
-        ptd::Push push{path_cnt + (bounce + 1) * ptd::kSegs, r.seg};
-        ptd::Push spush{shad_cnt + bounce * ptd::kSegs, r.seg};
+        uint32_t* shad_cnt = r.ln->counters + kCounterSets * kSetWords;
+        ptd::Live live = bounce == 0 ? ptd::Live{nullptr, 0, r.n_max, nullptr}
+                                     : ptd::Live{path_cnt + bounce * kSetWords, r.seg, r.cap, nullptr};
+        ptd::Push push{path_cnt + (bounce + 1) * kSetWords, r.seg};
+        ptd::Push spush{shad_cnt + bounce * kSetWords, r.seg};
         if (fused) {  // extend + shade in one kernel: nothing was launched by run_extend
             Timer t(s, r.st, PT_K_PATH);
             ptd::launch_path(s->dev, r.fr, bounce, r.ln->q[bounce & 1], live, r.ln->q[(bounce + 1) & 1], push, r.ln->sq,
@@ -681,7 +691,8 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
         }
         if (nee && bounce < P->max_bounces) {
             Timer t(s, r.st, PT_K_SHADOW);
-            ptd::launch_shadow(s->dev, r.ln->sq, ptd::Live{spush.counts, r.seg, r.cap}, r.ls, ctr, r.st);
+            uint32_t* cursors = s->persistent ? r.ln->counters + (3 * kCounterSets + bounce) * kSetWords : nullptr;
+            ptd::launch_shadow(s->dev, r.ln->sq, ptd::Live{spush.counts, r.seg, r.cap, cursors}, r.ls, ctr, r.st);
         }
     };
 
@@ -801,7 +812,7 @@ int pt_trace_closest(pt_scene* s, const pt_ray* rays, size_t n, uint32_t* tri_id
         hits.tri = (uint32_t*)(db + (size_t)9 * m);
         {
             Timer tm(s, nullptr, PT_K_EXTEND);
-            ptd::launch_extend(s->dev, q, db + (size_t)6 * m, db + (size_t)7 * m, ptd::Live{nullptr, 0, m}, hits,
+            ptd::launch_extend(s->dev, q, db + (size_t)6 * m, db + (size_t)7 * m, ptd::Live{nullptr, 0, m, nullptr}, hits,
                                s->d_ctr.as<ptd::Counters>(), s->profiling >= 2, nullptr);
         }
         ptd::launch_leaf_to_global(s->dev, hits.tri, m, nullptr);

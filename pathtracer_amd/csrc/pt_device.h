@@ -71,7 +71,7 @@ struct Scene {
     uint8_t vote_primary, vote_secondary, vote_shadow;
     uint8_t fuse;  // extend + shade of a bounce in one kernel where its rays go one per lane
     uint32_t wave_rays;
-    uint32_t pad;
+    uint32_t n_cu;  // compute units of the device (size of a persistent launch)
     Camera cam;
     double background[3];
 };
@@ -108,6 +108,9 @@ struct ShadowQueue {
 // appends to segment b % kSegs.  All segments fill evenly, entries stay dense inside a segment,
 // and a consumer workgroup (seg_size is a multiple of the block size) lies inside one segment.
 constexpr uint32_t kSegs = 64;
+// Every counter sits in its own 128-byte line: device-scope atomics are served at the memory side
+// and serialise per line, so 32 counters packed in one line share one counter's throughput.
+constexpr uint32_t kCtrStride = 32;  // words between the counters of neighbouring segments
 // extend / shadow: one wave works through a range of 64..kSegAlign consecutive entries (64 at a
 // time, a finished lane takes the next one).  Segment sizes are multiples of kSegAlign, so such a
 // range lies inside one segment.
@@ -116,6 +119,8 @@ struct Live {                 // which entries of a queue are live
     const uint32_t* counts;   // nullptr: dense, entries [0, n) are live
     uint32_t seg_size;        // segmented: entry i is live iff i % seg_size < counts[i / seg_size]
     uint32_t n;               // dense: live count; segmented: kSegs * seg_size (index range)
+    uint32_t* cursors;        // segmented, optional: kSegs work cursors (zeroed by the host) from which
+                              // persistent waves claim ranges of entries; nullptr = one range per wave
 };
 struct Push {                 // where survivors are appended
     uint32_t* counts;         // kSegs counters, zeroed by the host before the launch

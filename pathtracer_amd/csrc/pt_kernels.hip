@@ -230,16 +230,59 @@ __device__ __forceinline__ int node_step(const Scene& sc, int cur, D3 o, D3 inv,
 // of the 10M-triangle scene: every lane waited for the longest descent, the largest leaf and the
 // longest ray of its 64.
 // fetch(idx, o, d, t_min, t_max) loads ray idx; done(idx, leaf_tri, t) consumes its result.
+// Where a persistent wave gets its next range of queue entries from: the per-segment work cursors
+// of a segmented queue.  A wave starts on segment (wave id mod kSegs) and moves on round-robin when
+// a segment is used up; one atomic per claimed range, executed by one lane.  With cursors == nullptr
+// the wave owns exactly the range it was started with.
+struct RangePool {
+    uint32_t* cursors;
+    const uint32_t* counts;
+    uint32_t seg_size, grab, seg, tried;
+    __device__ __forceinline__ bool next(uint32_t& begin, uint32_t& end) {
+        if (!cursors) return false;
+        const uint32_t lane = threadIdx.x & 63u;
+        static_assert(kSegs == 64, "one lane looks at one segment");
+        // `tried` bounds the retries: a claim can lose a race, but every lost race means another wave
+        // took a range, and once a segment is seen empty it stays empty
+        while (tried < 4 * kSegs) {
+            // one coherent load per lane: which segments still have unclaimed entries?
+            const uint32_t live_k = min(counts[lane * kCtrStride], seg_size);
+            const uint32_t cur_k = __hip_atomic_load(&cursors[lane * kCtrStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long open = __ballot(cur_k < live_k);
+            if (!open) return false;
+            // first open segment at or after `seg`, cyclically
+            const unsigned long long rot = seg ? ((open >> seg) | (open << (64u - seg))) : open;
+            seg = (seg + (uint32_t)__builtin_ctzll(rot)) % kSegs;
+            const uint32_t live = (uint32_t)__builtin_amdgcn_readlane((int)live_k, (int)seg);
+            uint32_t c = 0;
+            if (lane == 0) c = atomicAdd(&cursors[seg * kCtrStride], grab);
+            c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+            if (c < live) {
+                begin = seg * seg_size + c;
+                end = seg * seg_size + min(c + grab, live);
+                return true;
+            }
+            ++tried;
+        }
+        return false;
+    }
+};
+
 template <int DEPTH, bool ANY, bool STATS, class Fetch, class Done>
-__device__ __forceinline__ void trace_range_vote(const Scene& sc, uint32_t begin, uint32_t end, int* stk, Fetch fetch,
-                                                 Done done, uint32_t& n_nodes, uint32_t& n_tris) {
+__device__ __forceinline__ void trace_range_vote(const Scene& sc, uint32_t begin, uint32_t end, RangePool pool, int* stk,
+                                                 Fetch fetch, Done done, uint32_t& n_nodes, uint32_t& n_tris) {
     uint32_t cursor = begin;  // wave-uniform: first unclaimed ray
+    bool more = pool.cursors != nullptr;  // wave-uniform: the pool may hold further ranges
     bool busy = false;
     uint32_t idx = 0, best = PT_MISS, best_id = PT_MISS;
     D3 o = mk(0., 0., 0.), d = o, inv = o;
     double t_min = 0., t_max = 0.;
     int sp = 0, cur = kDone;
     for (;;) {
+        if (more && cursor >= end) {  // the range is handed out: claim the next one (lanes still at work keep going)
+            more = pool.next(begin, end);
+            if (more) cursor = begin;
+        }
         const bool is_node = cur >= 0, is_ret = cur == kDone && (busy || cursor < end);
         const bool is_tri = cur < 0 && cur != kDone;
         const unsigned long long m_ret = __ballot(is_ret);
@@ -342,12 +385,12 @@ __device__ __forceinline__ uint32_t traverse(const Scene& sc, D3 o, D3 d, double
 __device__ __forceinline__ uint32_t live_end(const Live& lv, uint32_t i0) {
     if (!lv.counts) return lv.n;
     uint32_t seg = i0 / lv.seg_size;
-    return seg * lv.seg_size + min(lv.counts[seg], lv.seg_size);
+    return seg * lv.seg_size + min(lv.counts[seg * kCtrStride], lv.seg_size);
 }
 __device__ __forceinline__ unsigned long long live_total(const Live& lv) {
     if (!lv.counts) return lv.n;
     unsigned long long t = 0;
-    for (uint32_t k = 0; k < kSegs; ++k) t += min(lv.counts[k], lv.seg_size);
+    for (uint32_t k = 0; k < kSegs; ++k) t += min(lv.counts[k * kCtrStride], lv.seg_size);
     return t;
 }
 
@@ -380,7 +423,13 @@ __global__ __launch_bounds__(kTravBlock) void k_extend(Scene sc, Frame fr, Queue
     const uint32_t wib = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t block_rays = wave_rays * (kTravBlock / 64);
     uint32_t begin, end;
-    if (live.counts) {
+    RangePool pool{nullptr, nullptr, 0, 0, 0, 0};
+    if (VOTE && live.cursors) {
+        // persistent waves: ranges of wave_rays entries are claimed from the segments' work cursors
+        pool = RangePool{live.cursors, live.counts, live.seg_size, wave_rays,
+                         (blockIdx.x * (kTravBlock / 64) + wib) % kSegs, 0};
+        if (!pool.next(begin, end)) return;
+    } else if (live.counts) {
         // segmented queue: live entries are already spread evenly over the index range, and the
         // hardware's round-robin block placement spreads them over the XCDs
         begin = blockIdx.x * block_rays + wib * wave_rays;
@@ -413,7 +462,7 @@ __global__ __launch_bounds__(kTravBlock) void k_extend(Scene sc, Frame fr, Queue
             hits.t[i] = t;
         };
     if (VOTE) {
-        trace_range_vote<DEPTH, false, STATS>(sc, begin, end, stack + threadIdx.x, fetch, done, nn, nt);
+        trace_range_vote<DEPTH, false, STATS>(sc, begin, end, pool, stack + threadIdx.x, fetch, done, nn, nt);
     } else if (begin + lane < end) {  // wave_rays == 64
         uint32_t i = begin + lane;
         D3 o, d;
@@ -440,9 +489,17 @@ __global__ __launch_bounds__(kTravBlock) void k_shadow(Scene sc, ShadowQueue sq,
     __shared__ int stack[DEPTH * kTravBlock];
     if (ctr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->shadow_rays, live_total(live));
     const uint32_t lane = threadIdx.x & 63u;
-    uint32_t begin = (blockIdx.x * (kTravBlock / 64) + (threadIdx.x >> 6)) * wave_rays;
-    if (begin >= live.n) return;
-    uint32_t end = min(begin + wave_rays, live_end(live, begin));
+    uint32_t begin, end;
+    RangePool pool{nullptr, nullptr, 0, 0, 0, 0};
+    if (VOTE && live.cursors) {
+        pool = RangePool{live.cursors, live.counts, live.seg_size, wave_rays,
+                         (blockIdx.x * (kTravBlock / 64) + (threadIdx.x >> 6)) % kSegs, 0};
+        if (!pool.next(begin, end)) return;
+    } else {
+        begin = (blockIdx.x * (kTravBlock / 64) + (threadIdx.x >> 6)) * wave_rays;
+        if (begin >= live.n) return;
+        end = min(begin + wave_rays, live_end(live, begin));
+    }
     if (begin >= end) return;
     uint32_t nn = 0, nt = 0;
     auto fetch = [&](uint32_t i, D3& o, D3& d, double& t_min, double& t_max) {
@@ -460,7 +517,7 @@ __global__ __launch_bounds__(kTravBlock) void k_shadow(Scene sc, ShadowQueue sq,
             ls.c[2][slot] += sq.c[2][i];
         };
     if (VOTE) {
-        trace_range_vote<DEPTH, true, false>(sc, begin, end, stack + threadIdx.x, fetch, done, nn, nt);
+        trace_range_vote<DEPTH, true, false>(sc, begin, end, pool, stack + threadIdx.x, fetch, done, nn, nt);
     } else if (begin + lane < end) {  // wave_rays == 64
         uint32_t i = begin + lane;
         D3 o, d;
@@ -1026,10 +1083,10 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
         shade_vertex<FIRST, LAST, NEE, PLAIN, false>(sc, fr, bounce, in, i, leaf, t, mk(0., 0., 0.), mk(0., 0., 0.), ls, r);
     }
     if (LAST) return;  // nothing continues
-    uint32_t pos = region * out_push.seg_size + compact_slot(r.alive, out_push.counts + region, lds_a);
+    uint32_t pos = region * out_push.seg_size + compact_slot(r.alive, out_push.counts + region * kCtrStride, lds_a);
     if (r.alive) push_path<NEE>(out, pos, r);
     if (NEE) {
-        uint32_t spos = region * sq_push.seg_size + compact_slot(r.shadow, sq_push.counts + region, lds_b);
+        uint32_t spos = region * sq_push.seg_size + compact_slot(r.shadow, sq_push.counts + region * kCtrStride, lds_b);
         if (r.shadow) push_shadow(sq, spos, r);
     }
 }
@@ -1040,11 +1097,16 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
 // + 76 for the two-kernel form, and the FP64-bound traversal of one wave overlaps the HBM-bound
 // shading of its neighbours on the same SIMD.  One wave per workgroup; survivors are appended with
 // one atomic per wave to segment blockIdx % kSegs.
-constexpr int kPathBlock = 128;  // measured on CornellBox 1080p: 64 -> 9.38, 128 -> 11.09, 256 -> 10.93, 512 -> 9.90 Gsamples/s
+// Workgroup size of the fused kernel: 128 threads for shallow trees (measured on CornellBox 1080p:
+// 64 -> 9.38, 128 -> 11.09, 256 -> 10.93, 512 -> 9.90 Gsamples/s: one-wave workgroups are bound by
+// workgroup dispatch when every wave is short), one wave for deep trees (waves differ 10x in length;
+// LDS and registers are released per wave).
+template <int DEPTH> struct PathBlock { static constexpr int value = DEPTH <= 8 ? 128 : 64; };
 template <int DEPTH, bool FIRST, bool LAST, bool NEE, bool PLAIN>
-__global__ __launch_bounds__(kPathBlock) void k_path(Scene sc, Frame fr, uint32_t bounce, Queue in, Live live, Queue out,
+__global__ __launch_bounds__(PathBlock<DEPTH>::value) void k_path(Scene sc, Frame fr, uint32_t bounce, Queue in, Live live, Queue out,
                                                  Push out_push, ShadowQueue sq, Push sq_push, Sample3 ls,
                                                  Counters* ctr) {
+    constexpr int kPathBlock = PathBlock<DEPTH>::value;
     __shared__ int stack[DEPTH * kPathBlock];
     __shared__ uint32_t lds_a[kPathBlock / 64 + 1];
     __shared__ uint32_t lds_b[kPathBlock / 64 + 1];
@@ -1082,12 +1144,12 @@ __global__ __launch_bounds__(kPathBlock) void k_path(Scene sc, Frame fr, uint32_
     }
     if (LAST) return;  // nothing continues
     const uint32_t region = blockIdx.x % kSegs;
-    uint32_t pos = region * out_push.seg_size + (kPathBlock == 64 ? compact_wave(r.alive, out_push.counts + region)
-                                                                   : compact_slot<kPathBlock>(r.alive, out_push.counts + region, lds_a));
+    uint32_t pos = region * out_push.seg_size + (kPathBlock == 64 ? compact_wave(r.alive, out_push.counts + region * kCtrStride)
+                                                                   : compact_slot<kPathBlock>(r.alive, out_push.counts + region * kCtrStride, lds_a));
     if (r.alive) push_path<NEE>(out, pos, r);
     if (NEE) {
-        uint32_t spos = region * sq_push.seg_size + (kPathBlock == 64 ? compact_wave(r.shadow, sq_push.counts + region)
-                                                                      : compact_slot<kPathBlock>(r.shadow, sq_push.counts + region, lds_b));
+        uint32_t spos = region * sq_push.seg_size + (kPathBlock == 64 ? compact_wave(r.shadow, sq_push.counts + region * kCtrStride)
+                                                                      : compact_slot<kPathBlock>(r.shadow, sq_push.counts + region * kCtrStride, lds_b));
         if (r.shadow) push_shadow(sq, spos, r);
     }
 }
@@ -1188,11 +1250,17 @@ void launch_generate_rays(const Scene& sc, const Frame& fr, double* rays_out, hi
 }
 // The LDS stack is sized for the scene's BVH depth: 8 / 16 / 32 entries per lane (8 / 16 / 32 KB per
 // block), so shallow trees do not pay occupancy for stack they cannot use.
+// workgroups of a persistent launch: enough one-wave workgroups to fill every SIMD at the occupancy
+// the traversal kernels reach (<= 6 waves), whatever the queue holds
+static uint32_t persistent_blocks(const Scene& sc) {
+    return std::max(1u, sc.n_cu) * 4u * 6u / (kTravBlock / 64);
+}
 template <bool STATS, bool PRIMARY, bool VOTE>
 static void launch_extend_v(const Scene& sc, const Frame& fr, Queue q, const double* tmin, const double* tmax, Live live,
                             uint32_t wr, Hits hits, Counters* ctr, hipStream_t st) {
     const uint32_t br = wr * (kTravBlock / 64);  // rays per workgroup
     dim3 g(live.counts ? (live.n + br - 1) / br : trav_blocks(live.n, br)), b(kTravBlock);
+    if (VOTE && live.cursors) g.x = min(g.x, persistent_blocks(sc));
     if (sc.bvh_depth <= 8) hipLaunchKernelGGL((k_extend<8, STATS, PRIMARY, VOTE>), g, b, 0, st, sc, fr, q, tmin, tmax, live, wr, hits, ctr);
     else if (sc.bvh_depth <= 16 || getenv("PT_HACK16")) hipLaunchKernelGGL((k_extend<16, STATS, PRIMARY, VOTE>), g, b, 0, st, sc, fr, q, tmin, tmax, live, wr, hits, ctr);
     else hipLaunchKernelGGL((k_extend<32, STATS, PRIMARY, VOTE>), g, b, 0, st, sc, fr, q, tmin, tmax, live, wr, hits, ctr);
@@ -1266,6 +1334,7 @@ bool launch_path(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, Li
     if (!live.n) return true;
     bool nee = (fr.flags & PT_FLAG_NEE) != 0 && sc.n_lights > 0;
     bool first = bounce == 0, last = bounce >= fr.max_bounces;
+    const uint32_t kPathBlock = sc.bvh_depth <= 8 ? PathBlock<8>::value : PathBlock<32>::value;
     dim3 g(live.counts ? (live.n + kPathBlock - 1) / kPathBlock : trav_blocks(live.n, kPathBlock)), b(kPathBlock);
     #define PT_PATH(D, F, L) launch_path_t<D, F, L>(nee, g, b, st, sc, fr, bounce, in, live, out, out_push, sq, sq_push, ls, ctr)
     if (sc.bvh_depth <= 8) {
@@ -1285,6 +1354,7 @@ template <bool VOTE>
 static void launch_shadow_v(const Scene& sc, ShadowQueue sq, Live live, uint32_t wr, Sample3 ls, Counters* ctr, hipStream_t st) {
     const uint32_t br = wr * (kTravBlock / 64);
     dim3 g((live.n + br - 1) / br), b(kTravBlock);
+    if (VOTE && live.cursors) g.x = min(g.x, persistent_blocks(sc));
     if (sc.bvh_depth <= 8) hipLaunchKernelGGL((k_shadow<8, VOTE>), g, b, 0, st, sc, sq, live, wr, ls, ctr);
     else if (sc.bvh_depth <= 16) hipLaunchKernelGGL((k_shadow<16, VOTE>), g, b, 0, st, sc, sq, live, wr, ls, ctr);
     else hipLaunchKernelGGL((k_shadow<32, VOTE>), g, b, 0, st, sc, sq, live, wr, ls, ctr);
