@@ -189,6 +189,12 @@ __device__ __forceinline__ void prims_closest(const Scene& sc, D3 o, D3 d, doubl
         t_max = t;
     }
 }
+#ifdef PT_DEBUG_TAIL
+__device__ unsigned long long g_dbg_tail[16384];
+extern "C" int pt_debug_tail(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_tail), sizeof(unsigned long long) * 16384);
+}
+#endif
 constexpr int kDone = (int)0x80000000;
 template <int DEPTH, bool STATS, int STRIDE = kTravBlock>
 __device__ __forceinline__ int node_step(const Scene& sc, int cur, D3 o, D3 inv, double t_min, double t_max, int* stk,
@@ -254,12 +260,16 @@ struct RangePool {
             const unsigned long long rot = seg ? ((open >> seg) | (open << (64u - seg))) : open;
             seg = (seg + (uint32_t)__builtin_ctzll(rot)) % kSegs;
             const uint32_t live = (uint32_t)__builtin_amdgcn_readlane((int)live_k, (int)seg);
+            // guided schedule: full ranges while the segment is well stocked, smaller ones towards
+            // its end, so that the waves of a launch run dry at about the same time
+            const uint32_t rem = live - (uint32_t)__builtin_amdgcn_readlane((int)cur_k, (int)seg);
+            const uint32_t g = rem >= 32u * grab ? grab : (rem >= 8u * grab ? max(64u, grab / 2u) : 64u);
             uint32_t c = 0;
-            if (lane == 0) c = atomicAdd(&cursors[seg * kCtrStride], grab);
+            if (lane == 0) c = atomicAdd(&cursors[seg * kCtrStride], g);
             c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
             if (c < live) {
                 begin = seg * seg_size + c;
-                end = seg * seg_size + min(c + grab, live);
+                end = seg * seg_size + min(c + g, live);
                 return true;
             }
             ++tried;
@@ -462,7 +472,13 @@ __global__ __launch_bounds__(kTravBlock) void k_extend(Scene sc, Frame fr, Queue
             hits.t[i] = t;
         };
     if (VOTE) {
+#ifdef PT_DEBUG_TAIL
+        unsigned long long dbg_t0 = wall_clock64();
+#endif
         trace_range_vote<DEPTH, false, STATS>(sc, begin, end, pool, stack + threadIdx.x, fetch, done, nn, nt);
+#ifdef PT_DEBUG_TAIL
+        if (!STATS && live.cursors && lane == 0 && blockIdx.x < 8192) { g_dbg_tail[2 * blockIdx.x] = dbg_t0; g_dbg_tail[2 * blockIdx.x + 1] = wall_clock64(); }
+#endif
     } else if (begin + lane < end) {  // wave_rays == 64
         uint32_t i = begin + lane;
         D3 o, d;
