@@ -1001,7 +1001,7 @@ int orc_scene_create(const pt_scene_desc* d, orc_scene** out) {
         pr.radius = q.radius;
         sc.prims.push_back(pr);
     }
-    Builder(sc).run();
+    if (!getenv("ORC_NO_BVH")) Builder(sc).run();  // tests of 10 M-triangle scenes use the brute-force path only
     double acc = 0.;
     for (uint32_t i = 0; i < d->n_tris; ++i) {
         V3 le = emission_of(sc.mats[sc.tris[i].mat]);

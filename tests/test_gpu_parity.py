@@ -302,3 +302,80 @@ def test_fused_path_kernel_is_bitwise_identical(gpu, monkeypatch, name):
             cfg = pt.Config(width=83, height=47, samples_pr_pixel=3, bounces=bounces, seed=12, nee=nee, drop_nonfinite=True)
             a, b = plain.render(cfg), fused.render(cfg)
             assert a.tobytes() == b.tobytes(), (name, nee, bounces)
+
+
+def test_baseline_full_size_cornellbox_1080p(scenes):
+    # BASELINE.json configs[1] geometry at its full image size: primary hits bit-exact against the
+    # oracle on all 2,073,600 rays, and the size-independent properties of the accumulation
+    data, scene, oracle = scenes["CornellBox"]
+    cfg = pt.Config(width=1920, height=1080, samples_pr_pixel=8, bounces=2, seed=1, spp_per_batch=8)
+    rays = scene.generate_rays(cfg, 3)
+    assert rays.tobytes() == oracle.generate_rays(cfg, 3).tobytes()
+    tri, t = scene.trace_closest(rays)
+    rtri, rt = oracle.trace_closest(rays, use_bvh=True)
+    assert np.array_equal(tri, rtri) and np.array_equal(bits(t), bits(rt))
+    whole = scene.render(cfg)
+    # linearity in the sample range (frames are keyed by index and added in index order) ...
+    acc = scene.render(cfg, None, sample_begin=0, sample_count=3)
+    scene.render(cfg, acc, sample_begin=3, sample_count=5)
+    assert acc.tobytes() == whole.tobytes()
+    # ... tile decomposition (row bands as the multi-GPU `tiles` partitioning cuts them) ...
+    acc = np.zeros_like(whole)
+    for y0, y1 in ((0, 135), (135, 540), (540, 1080)):
+        scene.render(cfg, acc, tile=(0, y0, 1920, y1))
+    assert acc.tobytes() == whole.tobytes()
+    # ... idempotence of a repeated render, and energy: the mean radiance of the full-size image
+    # equals the oracle's on a strided subset of the same frames' pixels (same RNG streams)
+    assert scene.render(cfg).tobytes() == whole.tobytes()
+    ys, xs = slice(0, 1080, 36), slice(0, 1920, 1)           # 30 full rows
+    ref = np.zeros_like(whole)
+    for y in range(0, 1080, 36):
+        oracle.render(cfg, ref, tile=(0, y, 1920, y + 1), threads=16)
+    sub, rsub = whole[ys, xs], ref[ys, xs]
+    assert (np.abs(sub - rsub) > 1e-9 * np.maximum(1.0, np.abs(rsub))).mean() < 1e-3
+    assert abs(sub.mean() - rsub.mean()) <= 1e-6 * rsub.mean()
+
+
+def test_config5_full_size_heightfield_10m(gpu, monkeypatch):
+    # SURVEY config 5 at its full size (9,999,402 triangles, 3840x2160): no CPU oracle can render it
+    # in test time, so: a brute-force oracle slice of its primary rays (no tree on the CPU side),
+    # and the size-independent properties — scheduler invariance (vote-scheduled persistent waves vs
+    # one ray per lane, fused vs two-kernel, one vs two lanes), sample-range linearity, tiling.
+    from pathtracer_amd.synthetic import heightfield_box
+    data = heightfield_box()
+    assert data.n_tris == 9_999_402
+    scene = pt.Scene(data, gpu)
+    nodes, order, depth = scene.bvh()
+    assert depth <= 30 and len(order) == data.n_tris
+    cfg = pt.Config(width=3840, height=2160, samples_pr_pixel=2, bounces=2, seed=1, spp_per_batch=2)
+    rays = scene.generate_rays(cfg, 0)
+    tri, t = scene.trace_closest(rays)
+    hit = np.flatnonzero(tri != pt.PT_MISS)
+    assert 0.3 < len(hit) / len(tri) < 1.0                 # the box is open towards the camera
+    rng = np.random.default_rng(5)
+    pick = np.concatenate([rng.choice(hit, 12, replace=False), rng.choice(np.flatnonzero(tri == pt.PT_MISS), 4, replace=False)])
+    monkeypatch.setenv("ORC_NO_BVH", "1")                  # 10 M x 16 brute-force triangle tests, no CPU tree
+    brute = O.OracleScene(data)
+    monkeypatch.delenv("ORC_NO_BVH")
+    btri, bt = brute.trace_closest(rays[pick], use_bvh=False)
+    del brute
+    assert np.array_equal(tri[pick], btri) and np.array_equal(bits(t[pick]), bits(bt))
+    whole = scene.render(cfg)
+    assert np.isfinite(whole).all() and whole.mean() > 0.01
+    acc = scene.render(cfg, None, sample_begin=0, sample_count=1)
+    scene.render(cfg, acc, sample_begin=1, sample_count=1)
+    assert acc.tobytes() == whole.tobytes()
+    acc = np.zeros_like(whole)
+    for y0, y1 in ((0, 700), (700, 2160)):
+        scene.render(cfg, acc, tile=(0, y0, 3840, y1))
+    assert acc.tobytes() == whole.tobytes()
+    data.bvh_nodes, data.bvh_tri_order = nodes, order      # same tree, no second 10 M build
+    for env in (dict(PT_TRAV_VOTE="0", PT_TRAV_VOTE_SHADOW="0", PT_FUSE="0", PT_PIPELINE="0"),
+                dict(PT_PERSISTENT="0", PT_WAVE_RAYS="1024")):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        other = pt.Scene(data, gpu)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert other.render(cfg).tobytes() == whole.tobytes(), env
+        del other
