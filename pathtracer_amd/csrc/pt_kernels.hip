@@ -915,11 +915,22 @@ struct ShadeOut {
     D3 s_d, s_c;  // shadow ray direction and the radiance it carries if unoccluded
     double s_tmax = 0.;
 };
+// the part of a path record the shading needs besides the ray; the fused kernel loads it before
+// it walks the tree, so that the loads' latency is hidden behind the traversal
+struct PathRec {
+    uint32_t slot;
+    D3 T;
+};
+template <bool FIRST>
+__device__ __forceinline__ PathRec load_rec(const Queue& in, uint32_t i) {
+    if (FIRST) return {i, mk(1., 1., 1.)};
+    return {in.slot[i], mk(in.T[0][i], in.T[1][i], in.T[2][i])};
+}
 template <bool FIRST, bool LAST, bool NEE, bool PLAIN, bool FUSED>
 __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, uint32_t bounce, const Queue& in,
-                                             uint32_t i, uint32_t leaf, double t_hit, D3 o, D3 d, const Sample3& ls,
-                                             ShadeOut& r) {
-    const uint32_t slot = FIRST ? i : in.slot[i];
+                                             uint32_t i, PathRec rec, uint32_t leaf, double t_hit, D3 o, D3 d,
+                                             const Sample3& ls, ShadeOut& r) {
+    const uint32_t slot = rec.slot;
     r.slot = slot;
     uint32_t s = slot / fr.n_tile_pixels, p = slot - s * fr.n_tile_pixels;
     uint32_t ty = p / fr.tile_w, tx = p - ty * fr.tile_w;
@@ -936,7 +947,7 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
             d = mk(in.d[0][i], in.d[1][i], in.d[2][i]);
         }
     }
-    D3 T = FIRST ? mk(1., 1., 1.) : mk(in.T[0][i], in.T[1][i], in.T[2][i]);
+    D3 T = rec.T;
     D3 add;  // what main.rs:299 / :307 adds to color_result
     if (leaf == PT_MISS) {
         add = T * ld3(sc.background);  // main.rs:299
@@ -1096,7 +1107,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
         uint32_t leaf = hits.tri[i];
         // the hit distance is only needed (and only loaded) where the vertex is shaded in full
         double t = (leaf != PT_MISS && (!LAST || NEE)) ? hits.t[i] : 0.;
-        shade_vertex<FIRST, LAST, NEE, PLAIN, false>(sc, fr, bounce, in, i, leaf, t, mk(0., 0., 0.), mk(0., 0., 0.), ls, r);
+        shade_vertex<FIRST, LAST, NEE, PLAIN, false>(sc, fr, bounce, in, i, load_rec<FIRST>(in, i), leaf, t, mk(0., 0., 0.),
+                                                     mk(0., 0., 0.), ls, r);
     }
     if (LAST) return;  // nothing continues
     uint32_t pos = region * out_push.seg_size + compact_slot(r.alive, out_push.counts + region * kCtrStride, lds_a);
@@ -1153,10 +1165,11 @@ __global__ __launch_bounds__(PathBlock<DEPTH>::value) void k_path(Scene sc, Fram
             o = mk(in.o[0][i], in.o[1][i], in.o[2][i]);
             d = mk(in.d[0][i], in.d[1][i], in.d[2][i]);
         }
+        const PathRec rec = load_rec<FIRST>(in, i);  // in flight while the tree is walked
         double t = 1.7976931348623157e308;  // ray.rs:22 f64::MAX; t_min = 1e-5 (ray.rs:21)
         uint32_t nn = 0, nt = 0;
         uint32_t leaf = traverse<DEPTH, false, false, kPathBlock>(sc, o, d, 1e-5, t, stack + threadIdx.x, nn, nt);
-        shade_vertex<FIRST, LAST, NEE, PLAIN, true>(sc, fr, bounce, in, i, leaf, t, o, d, ls, r);
+        shade_vertex<FIRST, LAST, NEE, PLAIN, true>(sc, fr, bounce, in, i, rec, leaf, t, o, d, ls, r);
     }
     if (LAST) return;  // nothing continues
     const uint32_t region = blockIdx.x % kSegs;
