@@ -151,7 +151,7 @@ struct pt_scene {
     std::vector<uint32_t> order;
     uint32_t depth = 0;
     ptd::Scene dev{};
-    DevBuf d_nodes, d_tris, d_uvs, d_leaf_of, d_mats, d_texs, d_lights, d_prims, d_ctr;
+    DevBuf d_nodes, d_tris, d_uvs, d_leaf_of, d_mats, d_texs, d_lights, d_prims, d_tri_shade, d_ctr;
     std::vector<DevBuf*> d_texels;
     Workspace ws;
     std::mutex mu;
@@ -529,6 +529,11 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
     dv.lights = s->d_lights.as<ptd::Light>();
     dv.prims = s->d_prims.as<ptd::Prim>();
     dv.n_prims = d->n_prims;
+    dv.n_tris = d->n_tris;
+    HIP_TRY(s->d_tri_shade.alloc(std::max<size_t>(d->n_tris, 1) * sizeof(ptd::TriShade)));
+    dv.tri_shade = s->d_tri_shade.as<ptd::TriShade>();
+    ptd::launch_build_tri_shade(dv, s->d_tri_shade.as<ptd::TriShade>(), nullptr);
+    HIP_TRY(hipDeviceSynchronize());
     dv.n_nodes = d->n_tris ? (uint32_t)s->nodes.size() : 0u;
     dv.n_tris = d->n_tris;
     dv.n_lights = (uint32_t)lights.size();

@@ -44,6 +44,16 @@ struct Prim {  // analytic sphere / plane (geometry/mod.rs:20-29), SURVEY §8f N
     uint32_t mat;
 };
 
+// What shading needs of a hit triangle that does not depend on the ray: the unit geometric normal
+// of triangle_mesh.rs:141 (a cross product, a square root and three divisions per hit otherwise)
+// and the material id.  Built once on the device by the very function the kernels used to call, so
+// the bits are the same.  Leaf order, 32 bytes.
+struct TriShade {
+    double n[3];
+    uint32_t mat;
+    uint32_t pad;
+};
+
 struct Light {  // one emissive triangle, or (sphere != 0) an emissive sphere: v0 = centre, v1[0] = radius (NEE)
     double v0[3], v1[3], v2[3];
     double normal[3];  // unit geometric normal
@@ -57,6 +67,7 @@ struct Scene {
     const float4* nodes;
     const float4* tris;
     const float2* uvs;
+    const TriShade* tri_shade;  // [n_tris], leaf order
     const uint32_t* leaf_of;  // global triangle id -> leaf-order index
     const Material* mats;
     const Texture* texs;
@@ -168,6 +179,7 @@ bool launch_path(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, Li
                  ShadowQueue sq, Push sq_push, Sample3 lsample, Counters* ctr, hipStream_t st);
 void launch_accumulate(const Frame& fr, Sample3 lsample, double* accum, hipStream_t st);
 // parity entry points
+void launch_build_tri_shade(const Scene& sc, TriShade* out, hipStream_t st);
 void launch_leaf_to_global(const Scene& sc, uint32_t* tri, uint32_t n, hipStream_t st);
 void launch_sample_brdf(const Scene& sc, const Frame& fr, uint32_t bounce, const double* rays /* pt_ray[n] */,
                         const uint32_t* tri_leaf, const double* t, const uint32_t* pixel, uint32_t n, double* f,

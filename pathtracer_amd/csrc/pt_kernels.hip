@@ -830,28 +830,41 @@ struct ShadePoint {
     Brdf bs;
     D3 diffuse;  // Lambertian colour after the texture lookup (NEE evaluates the BRDF with it)
 };
-__device__ __forceinline__ void hit_geometry(const Scene& sc, uint32_t leaf, D3 o, D3 d, double t, TriV& tr,
-                                             uint32_t& mat, D3& position, D3& normal) {
+__device__ __forceinline__ TriV load_tri(const Scene& sc, uint32_t leaf) {
+    const float4* tp = sc.tris + (size_t)leaf * 3;
+    return widen(tp[0], tp[1], tp[2]);
+}
+// triangle_mesh.rs:141: normal = -(e0 x e1).normalize(), e0 = v1 - v0, e1 = v0 - v2
+__device__ __forceinline__ D3 tri_unit_normal(const TriV& tr) { return -normalize(cross(tr.v1 - tr.v0, tr.v0 - tr.v2)); }
+__global__ void k_build_tri_shade(Scene sc, TriShade* out) {
+    uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
+    if (leaf >= sc.n_tris) return;
+    D3 n = tri_unit_normal(load_tri(sc, leaf));
+    out[leaf].n[0] = n.x; out[leaf].n[1] = n.y; out[leaf].n[2] = n.z;
+    out[leaf].mat = (uint32_t)__float_as_int(sc.tris[(size_t)leaf * 3 + 1].w);
+    out[leaf].pad = 0;
+}
+__device__ __forceinline__ uint32_t hit_material(const Scene& sc, uint32_t leaf) {
+    return leaf >= PT_PRIM_BASE ? sc.prims[leaf - PT_PRIM_BASE].mat : sc.tri_shade[leaf].mat;
+}
+__device__ __forceinline__ void hit_geometry(const Scene& sc, uint32_t leaf, D3 o, D3 d, double t, uint32_t& mat,
+                                             D3& position, D3& normal) {
+    position = o + d * t;  // triangle_mesh.rs:140
     if (leaf >= PT_PRIM_BASE) {  // Surface::new(position, normal), geometry/mod.rs:46,71-72
         const Prim& pr = sc.prims[leaf - PT_PRIM_BASE];
-        tr.v0 = tr.v1 = tr.v2 = mk(0., 0., 0.);
         mat = pr.mat;
-        position = o + d * t;
         normal = pr.kind == PT_PRIM_PLANE ? ld3(pr.n) : normalize(position - ld3(pr.p));
         return;
     }
-    const float4* tp = sc.tris + (size_t)leaf * 3;
-    float4 a = tp[0], b = tp[1], c = tp[2];
-    tr = widen(a, b, c);
-    mat = (uint32_t)__float_as_int(b.w);
-    D3 gn = cross(tr.v1 - tr.v0, tr.v0 - tr.v2);
-    position = o + d * t;         // triangle_mesh.rs:140
-    normal = -normalize(gn);      // triangle_mesh.rs:141
+    const TriShade& ts = sc.tri_shade[leaf];
+    mat = ts.mat;
+    normal = ld3(ts.n);
 }
-__device__ __forceinline__ D3 diffuse_of(const Scene& sc, const Material& m, const TriV& tr, uint32_t leaf, D3 o,
+__device__ __forceinline__ D3 diffuse_of(const Scene& sc, const Material& m, uint32_t leaf, D3 o,
                                          D3 d, D3 position, D3 normal, const Frame& fr, bool primary,
                                          uint32_t pixel, uint32_t s) {
     if (m.tex < 0) return ld3(m.color);
+    const TriV tr = load_tri(sc, leaf);  // only a textured hit needs the vertices again (uv, dpdu, dpdv)
     bool has_diffs = primary && (fr.flags & PT_FLAG_USE_DIFFS);
     D3 rx = mk(0., 0., 0.), ry = rx;
     if (has_diffs) {  // scene.rs:47-54
@@ -952,17 +965,14 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
     if (leaf == PT_MISS) {
         add = T * ld3(sc.background);  // main.rs:299
     } else if (!kNeedRay) {
-        uint32_t mat = leaf >= PT_PRIM_BASE ? sc.prims[leaf - PT_PRIM_BASE].mat
-                                            : (uint32_t)__float_as_int(sc.tris[(size_t)leaf * 3 + 1].w);
-        const Material& m = sc.mats[mat];
+        const Material& m = sc.mats[hit_material(sc, leaf)];
         D3 le = (!PLAIN && m.kind != PT_MAT_LAMBERT) ? mk(0., 0., 0.) : ld3(m.emission);  // microfacet.rs:33-35; specular: none
         add = T * le;  // main.rs:307
     } else {
         const double t = t_hit;
-        TriV tr;
         uint32_t mat;
         D3 position, normal;
-        hit_geometry(sc, leaf, o, d, t, tr, mat, position, normal);
+        hit_geometry(sc, leaf, o, d, t, mat, position, normal);
         const Material& m = sc.mats[mat];
         D3 le = (!PLAIN && m.kind != PT_MAT_LAMBERT) ? mk(0., 0., 0.) : ld3(m.emission);  // microfacet.rs:33-35; specular: none
         add = T * le;  // main.rs:307
@@ -970,8 +980,9 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
             // MIS weight of a BRDF-sampled hit on a light (balance heuristic)
             // triangles emit from both faces (main.rs:307 adds Le on any hit), spheres from outside
             // only (lights.rs:47-49)
-            double cos_l = leaf >= PT_PRIM_BASE ? dot(normal, -d)
-                                                : fabs(dot(normalize(cross(tr.v1 - tr.v0, tr.v2 - tr.v0)), d));
+            // (the light's own normal (v1-v0) x (v2-v0), normalised, is -(e0 x e1) normalised = `normal`
+            // bit for bit: negation commutes exactly with the cross product and the normalisation)
+            double cos_l = leaf >= PT_PRIM_BASE ? dot(normal, -d) : fabs(dot(normal, d));
             double p_l = cos_l <= 0. ? 0. : t * t / (sc.light_area * cos_l);
             double pp = in.prev_pdf[i];
             double wgt = pp > 0. ? pp / (pp + p_l) : (pp < 0. ? 1. : 0.);  // pp < 0: specular predecessor
@@ -980,7 +991,7 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
         if (!LAST) {
             D3 diffuse = mk(0., 0., 0.);
             if (PLAIN) diffuse = ld3(m.color);
-            else if (m.kind == PT_MAT_LAMBERT) diffuse = diffuse_of(sc, m, tr, leaf, o, d, position, normal, fr, FIRST, pixel, s);
+            else if (m.kind == PT_MAT_LAMBERT) diffuse = diffuse_of(sc, m, leaf, o, d, position, normal, fr, FIRST, pixel, s);
             if (NEE && sc.n_lights) {
                 double r0, r1;
                 uniform2(fr.seed, pixel, sample, bounce, STREAM_LIGHT, r0, r1);
@@ -1232,14 +1243,13 @@ __global__ void k_sample_brdf(Scene sc, Frame fr, uint32_t bounce, const double*
     const double* r = rays + (size_t)i * 8;
     D3 o = mk(r[0], r[1], r[2]), d = mk(r[3], r[4], r[5]);
     uint32_t leaf = tri_global[i] >= PT_PRIM_BASE ? tri_global[i] : sc.leaf_of[tri_global[i]];
-    TriV tr;
     uint32_t mat;
     D3 position, normal;
-    hit_geometry(sc, leaf, o, d, tt[i], tr, mat, position, normal);
+    hit_geometry(sc, leaf, o, d, tt[i], mat, position, normal);
     const Material& m = sc.mats[mat];
     uint32_t pixel = pixel_in[i];
     D3 diffuse = mk(0., 0., 0.);
-    if (m.kind == PT_MAT_LAMBERT) diffuse = diffuse_of(sc, m, tr, leaf, o, d, position, normal, fr, bounce == 0, pixel, 0);
+    if (m.kind == PT_MAT_LAMBERT) diffuse = diffuse_of(sc, m, leaf, o, d, position, normal, fr, bounce == 0, pixel, 0);
     double xi1, xi2;
     uniform2(fr.seed, pixel, fr.sample_base, bounce, STREAM_BRDF, xi1, xi2);
     Brdf bs;
@@ -1396,6 +1406,10 @@ void launch_shadow(const Scene& sc, ShadowQueue sq, Live live, Sample3 ls, Count
 void launch_accumulate(const Frame& fr, Sample3 ls, double* accum, hipStream_t st) {
     if (!fr.n_tile_pixels) return;
     hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(fr.n_tile_pixels)), dim3(kBlock), 0, st, fr, ls, accum);
+}
+void launch_build_tri_shade(const Scene& sc, TriShade* out, hipStream_t st) {
+    if (!sc.n_tris) return;
+    hipLaunchKernelGGL(k_build_tri_shade, dim3(blocks_for(sc.n_tris)), dim3(kBlock), 0, st, sc, out);
 }
 void launch_leaf_to_global(const Scene& sc, uint32_t* tri, uint32_t n, hipStream_t st) {
     if (!n) return;
