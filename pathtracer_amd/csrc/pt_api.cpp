@@ -151,7 +151,7 @@ struct pt_scene {
     std::vector<uint32_t> order;
     uint32_t depth = 0;
     ptd::Scene dev{};
-    DevBuf d_nodes, d_tris, d_uvs, d_leaf_of, d_mats, d_texs, d_lights, d_prims, d_tri_shade, d_ctr;
+    DevBuf d_nodes, d_tris, d_uvs, d_leaf_of, d_mats, d_texs, d_lights, d_prims, d_tri_shade, d_eye_nodes, d_eye_tris, d_ctr;
     std::vector<DevBuf*> d_texels;
     Workspace ws;
     std::mutex mu;
@@ -529,11 +529,6 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
     dv.lights = s->d_lights.as<ptd::Light>();
     dv.prims = s->d_prims.as<ptd::Prim>();
     dv.n_prims = d->n_prims;
-    dv.n_tris = d->n_tris;
-    HIP_TRY(s->d_tri_shade.alloc(std::max<size_t>(d->n_tris, 1) * sizeof(ptd::TriShade)));
-    dv.tri_shade = s->d_tri_shade.as<ptd::TriShade>();
-    ptd::launch_build_tri_shade(dv, s->d_tri_shade.as<ptd::TriShade>(), nullptr);
-    HIP_TRY(hipDeviceSynchronize());
     dv.n_nodes = d->n_tris ? (uint32_t)s->nodes.size() : 0u;
     dv.n_tris = d->n_tris;
     dv.n_lights = (uint32_t)lights.size();
@@ -561,6 +556,22 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
     dv.cam.view_dir[0] = view.x * cc; dv.cam.view_dir[1] = view.y * cc; dv.cam.view_dir[2] = view.z * cc;
     dv.cam.axes0[0] = a0.x; dv.cam.axes0[1] = a0.y; dv.cam.axes0[2] = a0.z;
     dv.cam.axes1[0] = a1.x; dv.cam.axes1[1] = a1.y; dv.cam.axes1[2] = a1.z;
+    // ---- ray-independent tables, built on the device with the kernels' own arithmetic
+    dv.n_tris = d->n_tris;
+    HIP_TRY(s->d_tri_shade.alloc(std::max<size_t>(d->n_tris, 1) * sizeof(ptd::TriShade)));
+    dv.tri_shade = s->d_tri_shade.as<ptd::TriShade>();
+    ptd::launch_build_tri_shade(dv, s->d_tri_shade.as<ptd::TriShade>(), nullptr);
+    dv.eye_nodes = nullptr;
+    dv.eye_tris = nullptr;
+    const char* eye_env = getenv("PT_EYE_TABLES");
+    if (dv.n_nodes && d->n_tris <= ptd::kEyeTableMaxTris && !(eye_env && atoi(eye_env) == 0)) {
+        HIP_TRY(s->d_eye_nodes.alloc(s->nodes.size() * sizeof(ptd::EyeNode)));
+        HIP_TRY(s->d_eye_tris.alloc((size_t)d->n_tris * sizeof(ptd::EyeTri)));
+        ptd::launch_build_eye_tables(dv, s->d_eye_nodes.as<ptd::EyeNode>(), s->d_eye_tris.as<ptd::EyeTri>(), nullptr);
+        dv.eye_nodes = s->d_eye_nodes.as<ptd::EyeNode>();
+        dv.eye_tris = s->d_eye_tris.as<ptd::EyeTri>();
+    }
+    HIP_TRY(hipDeviceSynchronize());
     for (int a = 0; a < 3; ++a) dv.background[a] = d->background[a];
 
     *out = s.release();

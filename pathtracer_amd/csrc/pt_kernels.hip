@@ -107,16 +107,30 @@ __device__ __forceinline__ TriV widen(float4 a, float4 b, float4 c) {
     return {mk((double)a.x, (double)a.y, (double)a.z), mk((double)b.x, (double)b.y, (double)b.z),
             mk((double)c.x, (double)c.y, (double)c.z)};
 }
-__device__ __forceinline__ bool tri_test(const TriV& tr, D3 o, D3 d, double t_min, double t_max, double& t_out,
-                                         double& v_out, double& w_out) {
-    D3 e0 = tr.v1 - tr.v0;
-    D3 e1 = tr.v0 - tr.v2;
-    D3 normal = cross(e0, e1);
-    double dn = dot(d, normal);
+__device__ __forceinline__ TriV load_tri(const Scene& sc, uint32_t leaf) {
+    const float4* tp = sc.tris + (size_t)leaf * 3;
+    return widen(tp[0], tp[1], tp[2]);
+}
+// the ray-direction-independent part of the test
+struct TriPre {
+    D3 e0, e1, normal, vo;
+    double num;
+};
+__device__ __forceinline__ TriPre tri_pre(const TriV& tr, D3 o) {
+    TriPre p;
+    p.e0 = tr.v1 - tr.v0;
+    p.e1 = tr.v0 - tr.v2;
+    p.normal = cross(p.e0, p.e1);
+    p.vo = tr.v0 - o;
+    p.num = dot(p.vo, p.normal);
+    return p;
+}
+__device__ __forceinline__ bool tri_test_core(const TriPre& p, D3 d, double t_min, double t_max, double& t_out,
+                                              double& v_out, double& w_out) {
+    double dn = dot(d, p.normal);
     if (fabs(dn) < 1.0e-12) return false;
-    D3 vo = tr.v0 - o;
-    D3 tmp = cross(vo, d);
-    double a = dot(tmp, e1), b = dot(tmp, e0), num = dot(vo, normal);
+    D3 tmp = cross(p.vo, d);
+    double a = dot(tmp, p.e1), b = dot(tmp, p.e0), num = p.num;
     // Division-free exact rejects.  With |x| >= 2^-500 and 1e-12 <= |dn| <= 2^500 neither
     // x * (1/dn) nor x / dn can round to zero, so their sign is sign(x) * sign(dn): the reference's
     // `v < 0`, `w < 0` and (for t_min >= 0) `t < t_min` are decided without dividing.  NaNs and
@@ -135,6 +149,10 @@ __device__ __forceinline__ bool tri_test(const TriV& tr, D3 o, D3 d, double t_mi
     if (t < t_min || t > t_max) return false;
     t_out = t; v_out = v; w_out = w;
     return true;
+}
+__device__ __forceinline__ bool tri_test(const TriV& tr, D3 o, D3 d, double t_min, double t_max, double& t_out,
+                                         double& v_out, double& w_out) {
+    return tri_test_core(tri_pre(tr, o), d, t_min, t_max, t_out, v_out, w_out);
 }
 
 // f64 slab test against an f32 box that the builder padded outward.  v_min/v_max_f64 return the
@@ -382,6 +400,86 @@ __device__ __forceinline__ uint32_t traverse(const Scene& sc, D3 o, D3 d, double
             if (best != PT_MISS && !(t < t_max || gid < best_id)) continue;
             best = first + k; best_id = gid; t_max = t;
             if (ANY) return best;
+        }
+        if (sp == 0) break;
+        --sp;
+        cur = stk[sp * STRIDE];
+    }
+    return best;
+}
+
+// ---- primary rays of a small scene: the eye-relative tables (pt_device.h EyeNode / EyeTri) -----
+__device__ __forceinline__ bool slab_rel(const double* r, D3 inv, double t_min, double t_max, double& t_near) {
+    double ax = r[0] * inv.x, bx = r[3] * inv.x;   // r = (lo - o, hi - o): the subtraction of slab() is in the table
+    double ay = r[1] * inv.y, by = r[4] * inv.y;
+    double az = r[2] * inv.z, bz = r[5] * inv.z;
+    double tn = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmax(fmin(az, bz), t_min));
+    double tf = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmin(fmax(az, bz), t_max));
+    t_near = tn;
+    return tn <= tf;
+}
+__global__ void k_build_eye_tables(Scene sc, EyeNode* nodes, EyeTri* tris) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const D3 o = ld3(sc.cam.eye);
+    if (i < sc.n_nodes) {
+        const float4* np = sc.nodes + (size_t)i * 4;
+        float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+        const float b[12] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w};
+        const double oo[3] = {o.x, o.y, o.z};
+        for (int k = 0; k < 12; ++k) nodes[i].rel[k] = (double)b[k] - oo[k % 3];
+        nodes[i].child[0] = __float_as_int(n3.x);
+        nodes[i].child[1] = __float_as_int(n3.y);
+        nodes[i].pad[0] = nodes[i].pad[1] = 0;
+    }
+    if (i < sc.n_tris) {
+        TriPre p = tri_pre(load_tri(sc, i), o);
+        EyeTri& e = tris[i];
+        e.e0[0] = p.e0.x; e.e0[1] = p.e0.y; e.e0[2] = p.e0.z;
+        e.e1[0] = p.e1.x; e.e1[1] = p.e1.y; e.e1[2] = p.e1.z;
+        e.normal[0] = p.normal.x; e.normal[1] = p.normal.y; e.normal[2] = p.normal.z;
+        e.vo[0] = p.vo.x; e.vo[1] = p.vo.y; e.vo[2] = p.vo.z;
+        e.num = p.num;
+        e.gid = (uint32_t)__float_as_int(sc.tris[(size_t)i * 3].w);
+        e.pad = 0;
+    }
+}
+// traverse() for a ray that starts at the eye (closest hit only)
+template <int DEPTH, int STRIDE>
+__device__ __forceinline__ uint32_t traverse_eye(const Scene& sc, D3 d, double t_min, double& t_max, int* stk) {
+    uint32_t best = PT_MISS, best_id = PT_MISS;
+    if (sc.n_prims) prims_closest(sc, ld3(sc.cam.eye), d, t_min, t_max, best, best_id);
+    if (sc.n_nodes == 0) return best;
+    D3 inv = mk(1. / d.x, 1. / d.y, 1. / d.z);
+    int sp = 0;
+    int cur = 0;
+    while (cur != kDone) {
+        while (cur >= 0) {
+            const EyeNode& n = sc.eye_nodes[cur];
+            int c0 = n.child[0], c1 = n.child[1];
+            double tn0, tn1;
+            bool h0 = slab_rel(n.rel, inv, t_min, t_max, tn0) && c0 != PT_BVH_EMPTY;
+            bool h1 = slab_rel(n.rel + 6, inv, t_min, t_max, tn1) && c1 != PT_BVH_EMPTY;
+            if (h0 && h1) {
+                int nearc = c0, farc = c1;
+                if (tn1 < tn0) { nearc = c1; farc = c0; }
+                if (sp < DEPTH) { stk[sp * STRIDE] = farc; ++sp; }
+                cur = nearc;
+            } else if (h0) cur = c0;
+            else if (h1) cur = c1;
+            else if (sp == 0) cur = kDone;
+            else { --sp; cur = stk[sp * STRIDE]; }
+        }
+        if (cur == kDone) break;
+        int code = ~cur;
+        uint32_t first = (uint32_t)code >> 3, cnt = ((uint32_t)code & 7u) + 1u;
+        for (uint32_t k = 0; k < cnt; ++k) {
+            const EyeTri& e = sc.eye_tris[first + k];
+            TriPre p{ld3(e.e0), ld3(e.e1), ld3(e.normal), ld3(e.vo), e.num};
+            double t, v, w;
+            if (!tri_test_core(p, d, t_min, t_max, t, v, w)) continue;
+            uint32_t gid = e.gid;
+            if (best != PT_MISS && !(t < t_max || gid < best_id)) continue;  // lowest id wins a tie, as in traverse()
+            best = first + k; best_id = gid; t_max = t;
         }
         if (sp == 0) break;
         --sp;
@@ -830,10 +928,6 @@ struct ShadePoint {
     Brdf bs;
     D3 diffuse;  // Lambertian colour after the texture lookup (NEE evaluates the BRDF with it)
 };
-__device__ __forceinline__ TriV load_tri(const Scene& sc, uint32_t leaf) {
-    const float4* tp = sc.tris + (size_t)leaf * 3;
-    return widen(tp[0], tp[1], tp[2]);
-}
 // triangle_mesh.rs:141: normal = -(e0 x e1).normalize(), e0 = v1 - v0, e1 = v0 - v2
 __device__ __forceinline__ D3 tri_unit_normal(const TriV& tr) { return -normalize(cross(tr.v1 - tr.v0, tr.v0 - tr.v2)); }
 __global__ void k_build_tri_shade(Scene sc, TriShade* out) {
@@ -1179,7 +1273,8 @@ __global__ __launch_bounds__(PathBlock<DEPTH>::value) void k_path(Scene sc, Fram
         const PathRec rec = load_rec<FIRST>(in, i);  // in flight while the tree is walked
         double t = 1.7976931348623157e308;  // ray.rs:22 f64::MAX; t_min = 1e-5 (ray.rs:21)
         uint32_t nn = 0, nt = 0;
-        uint32_t leaf = traverse<DEPTH, false, false, kPathBlock>(sc, o, d, 1e-5, t, stack + threadIdx.x, nn, nt);
+        uint32_t leaf = (FIRST && sc.eye_nodes) ? traverse_eye<DEPTH, kPathBlock>(sc, d, 1e-5, t, stack + threadIdx.x)
+                                                : traverse<DEPTH, false, false, kPathBlock>(sc, o, d, 1e-5, t, stack + threadIdx.x, nn, nt);
         shade_vertex<FIRST, LAST, NEE, PLAIN, true>(sc, fr, bounce, in, i, rec, leaf, t, o, d, ls, r);
     }
     if (LAST) return;  // nothing continues
@@ -1406,6 +1501,11 @@ void launch_shadow(const Scene& sc, ShadowQueue sq, Live live, Sample3 ls, Count
 void launch_accumulate(const Frame& fr, Sample3 ls, double* accum, hipStream_t st) {
     if (!fr.n_tile_pixels) return;
     hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(fr.n_tile_pixels)), dim3(kBlock), 0, st, fr, ls, accum);
+}
+void launch_build_eye_tables(const Scene& sc, EyeNode* nodes, EyeTri* tris, hipStream_t st) {
+    uint32_t n = std::max(sc.n_nodes, sc.n_tris);
+    if (!n) return;
+    hipLaunchKernelGGL(k_build_eye_tables, dim3(blocks_for(n)), dim3(kBlock), 0, st, sc, nodes, tris);
 }
 void launch_build_tri_shade(const Scene& sc, TriShade* out, hipStream_t st) {
     if (!sc.n_tris) return;

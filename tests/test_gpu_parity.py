@@ -379,3 +379,21 @@ def test_config5_full_size_heightfield_10m(gpu, monkeypatch):
             monkeypatch.delenv(k)
         assert other.render(cfg).tobytes() == whole.tobytes(), env
         del other
+
+
+@pytest.mark.parametrize("name", ["CornellBox", "Test", "glossy_planes", "heightfield40"])
+def test_eye_tables_are_bitwise_identical(gpu, monkeypatch, name):
+    # primary rays traced through the eye-relative tables (hoisted origin-dependent arithmetic) against
+    # the general traversal: the same bits, images included
+    if name == "heightfield40":
+        from pathtracer_amd.synthetic import heightfield_box
+        data = heightfield_box(cells=40)
+    else:
+        data = pt.scene_data(name, textures=True) if name == "Test" else pt.scene_data(name)
+    monkeypatch.setenv("PT_EYE_TABLES", "0")
+    general = pt.Scene(data, gpu)
+    monkeypatch.delenv("PT_EYE_TABLES")
+    tables = pt.Scene(data, gpu)
+    for cfg in (pt.Config(width=211, height=97, samples_pr_pixel=3, bounces=2, seed=5, drop_nonfinite=True),
+                pt.Config(dim=64, samples_pr_pixel=2, bounces=0, seed=1, nee=True, drop_nonfinite=True)):
+        assert general.render(cfg).tobytes() == tables.render(cfg).tobytes(), (name, cfg)
