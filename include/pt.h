@@ -152,8 +152,15 @@ enum {
     PT_FLAG_RUSSIAN_ROULETTE = 1u << 3, /* legacy integrator main.rs:85-111: from the 5th path vertex
                                          * on a Lambertian vertex continues with probability
                                          * mean(albedo) and the throughput is divided by it */
-    PT_FLAG_DROP_NONFINITE = 1u << 2 /* drop NaN/inf samples instead of accumulating them
-                                        (deviation from main.rs:434-436; off by default) */
+    PT_FLAG_DROP_NONFINITE = 1u << 2, /* drop NaN/inf samples instead of accumulating them
+                                         (deviation from main.rs:434-436; off by default) */
+    PT_FLAG_PROPAGATE_DIFFS = 1u << 4, /* legacy reflect_diff / refract_diff (main.rs:192-281): the ray
+                                        * spawned at a vertex carries differentials, so textures on
+                                        * secondary hits are filtered (the live render() resets them,
+                                        * main.rs:314).  Needs PT_FLAG_USE_DIFFS; ignored by scenes
+                                        * without textures, where nothing reads a differential */
+    PT_FLAG_ROUGHDIFF = 1u << 5 /* CONFIG.roughdiff (main.rs:351): a Glossy vertex spreads the
+                                 * differentials by diff_size * roughness / 0.8 (main.rs:249-253) */
 };
 
 /* CONFIG of main.rs:320-379 plus the partitioning knobs of SURVEY.md §8e. */
@@ -166,6 +173,8 @@ typedef struct pt_render_params {
     uint32_t flags;           /* PT_FLAG_* */
     uint32_t spp_per_batch;   /* frames kept in flight per wavefront pass; 0 = auto */
     uint64_t seed;            /* key of the counter-based RNG that replaces rand::random (F8) */
+    double diff_size;         /* CONFIG.diff_size, default 0 (main.rs:348): spread of the differential
+                               * rays spawned at Lambertian / Glossy vertices (PT_FLAG_PROPAGATE_DIFFS) */
 } pt_render_params;
 
 typedef struct pt_kernel_stat {

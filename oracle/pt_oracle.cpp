@@ -402,6 +402,7 @@ struct Material {
 struct BrdfSample {
     V3 f, wi;
     double pdf;
+    int lobe = 0;  // 1: specular reflection, 2: refraction (selects reflect_diff / refract_diff)
 };
 
 // material.rs:9-23 sample_cosine_weighted_hemisphere (draw order: rnd, then phi's draw)
@@ -755,14 +756,14 @@ inline BrdfSample sample_brdf(const Scene& sc, const Material& m, const Surface&
                               double xi2) {
     if (is_glossy(m.kind)) return glossy_sample(m.color, m.roughness, ray_dir, s.normal, xi1, xi2, m.kind == PT_MAT_GLOSSY_GGX);
     if (m.kind == PT_MAT_MIRROR)  // main.rs:178-185
-        return {v3(1, 1, 1), reflect(ray_dir, s.normal), -1.};
+        return {v3(1, 1, 1), reflect(ray_dir, s.normal), -1., 1};
     if (m.kind == PT_MAT_TRANSPARENT) {  // main.rs:117-142, one of the two branches by Fresnel weight
         double cos_theta = dot(-ray_dir, s.normal);
         double eta = cos_theta < 0. ? m.ior / 1. : 1. / m.ior;  // FresnelDielectric::eta, microfacet.rs:318-326
         double fresnel_r = dielectric(m.ior, cos_theta);
         V3 normal = cos_theta < 0. ? -s.normal : s.normal;
-        if (xi1 < fresnel_r) return {v3(1, 1, 1), reflect(ray_dir, normal), -1.};
-        return {v3(1, 1, 1), refract(ray_dir, normal, eta), -1.};
+        if (xi1 < fresnel_r) return {v3(1, 1, 1), reflect(ray_dir, normal), -1., 1};
+        return {v3(1, 1, 1), refract(ray_dir, normal, eta), -1., 2};
     }
     return lambertian_sample(get_diffuse(sc, m, s), s.normal, xi1, xi2);
 }
@@ -817,11 +818,58 @@ inline Surface prim_surface(const Prim& pr, const Ray& ray, double t) {
     return s;
 }
 
+// vec3.rs:175-184 create_tangent_vectors
+inline void create_tangent_vectors(V3 s, V3& v2, V3& v3_) {
+    if (std::fabs(s.x) > std::fabs(s.y)) v2 = v3(-s.z, 0., s.x) / std::sqrt(s.x * s.x + s.z * s.z);
+    else v2 = v3(0., s.z, -s.y) / std::sqrt(s.y * s.y + s.z * s.z);
+    v3_ = cross(s, v2);
+}
+// The ray the legacy integrator spawns at a vertex (main.rs:192-281, commented out there):
+// reflect_diff for Lambertian / Glossy / Mirror and the reflected branch of Transparent,
+// refract_diff for the refracted branch.  surface.dndu = surface.dndv = 0 on every surface the
+// reference's triangles and Surface::new build (surface.rs:40-41; triangle_mesh.rs never sets
+// them), so dndx = dndy = 0 and the terms they multiply (which add only signed zeros) are dropped.
+inline Ray spawn_with_diffs(const Surface& s, const Ray& inc, const Material& m, const BrdfSample& bs,
+                            const pt_render_params& P) {
+    Ray nr(s.position, bs.wi);
+    V3 wo = -inc.direction;
+    V3 wi = nr.direction;
+    nr.rx_origin = s.position + s.dpdx;
+    nr.ry_origin = s.position + s.dpdy;
+    if (bs.lobe == 0) {  // main.rs:242-257
+        double diff_size = P.diff_size;
+        if (is_glossy(m.kind) && (P.flags & PT_FLAG_ROUGHDIFF)) diff_size = P.diff_size * m.roughness / 0.8;
+        V3 v0, v1;
+        create_tangent_vectors(wi, v0, v1);
+        nr.rx_direction = normalize(wi + diff_size * v0);
+        nr.ry_direction = normalize(wi + diff_size * v1);
+        return nr;
+    }
+    double cos_theta = dot(wo, s.normal);
+    V3 normal = cos_theta < 0. ? -s.normal : s.normal;
+    V3 dwodx = -inc.rx_direction - wo;
+    V3 dwody = -inc.ry_direction - wo;
+    double dDNdx = dot(dwodx, normal);
+    double dDNdy = dot(dwody, normal);
+    if (bs.lobe == 1) {  // main.rs:258-276
+        nr.rx_direction = wi - dwodx + 2. * (dDNdx * normal);
+        nr.ry_direction = wi - dwody + 2. * (dDNdy * normal);
+    } else {  // main.rs:198-221 as written (pbrt-v3's form; its signs are not those of d(refract), kept as the reference has them)
+        double eta = cos_theta < 0. ? m.ior / 1. : 1. / m.ior;
+        double dmudx = (eta - (eta * eta * dot(-wo, normal)) / dot(wi, normal)) * dDNdx;
+        double dmudy = (eta - (eta * eta * dot(-wo, normal)) / dot(wi, normal)) * dDNdy;
+        nr.rx_direction = wi + eta * dwodx - dmudx * normal;
+        nr.ry_direction = wi + eta * dwody - dmudy * normal;
+    }
+    return nr;
+}
+
 // main.rs:283-318 render()
 inline V3 render(const Scene& sc, double x, double y, double pdx, double pdy, uint32_t pixel, uint64_t sample,
                  const pt_render_params& P, bool bvh) {
     bool use_diffs = (P.flags & PT_FLAG_USE_DIFFS) != 0;
     bool nee = (P.flags & PT_FLAG_NEE) != 0 && !sc.lights.empty();
+    bool propagate = use_diffs && (P.flags & PT_FLAG_PROPAGATE_DIFFS) != 0 && !sc.texs.empty();
     Ray trace_ray = camera_ray(sc.cam, x, y, pdx, pdy, use_diffs);
     V3 color_result = v3(0, 0, 0);
     uint32_t bounces = 0;
@@ -927,7 +975,7 @@ inline V3 render(const Scene& sc, double x, double y, double pdx, double pdy, ui
             prev_pdf = bs.pdf > 0. ? bs.pdf : 0.;
         }
         if (luminance != 1.) accumulated_pdf = accumulated_pdf / luminance;
-        trace_ray = Ray(surface.position, bs.wi);
+        trace_ray = propagate ? spawn_with_diffs(surface, hit_ray, m, bs, P) : Ray(surface.position, bs.wi);
     }
     return color_result;
 }
@@ -1201,6 +1249,26 @@ void orc_normalize(const double v[3], double* out3) {
 void orc_rotate_to(const double v[3], const double n[3], double* out3) {
     V3 r = rotate_to(v3(v[0], v[1], v[2]), v3(n[0], n[1], n[2]));
     out3[0] = r.x; out3[1] = r.y; out3[2] = r.z;
+}
+// main.rs:192-281 reflect_diff / refract_diff on one vertex.  in18: surface position, normal, dpdx,
+// dpdy, then the incident ray's direction, rx_direction, ry_direction (3 doubles each), wi last is
+// separate; out12: rx_origin, ry_origin, rx_direction, ry_direction of the spawned ray.
+// lobe: 0 diffuse / glossy sample, 1 specular reflection, 2 refraction.
+void orc_spawn_diffs(const double* in21, const double wi[3], int kind, int lobe, double roughness, double ior,
+                     double diff_size, uint32_t flags, double* out12) {
+    auto at = [&](int k) { return v3(in21[3 * k], in21[3 * k + 1], in21[3 * k + 2]); };
+    Surface s;
+    s.position = at(0); s.normal = at(1); s.dpdx = at(2); s.dpdy = at(3);
+    Ray inc(v3(0, 0, 0), at(4));
+    inc.rx_direction = at(5); inc.ry_direction = at(6);
+    Material m{kind, v3(0, 0, 0), v3(0, 0, 0), roughness, -1, ior};
+    BrdfSample bs{v3(1, 1, 1), v3(wi[0], wi[1], wi[2]), lobe ? -1. : 1., lobe};
+    pt_render_params P{};
+    P.flags = flags;
+    P.diff_size = diff_size;
+    Ray r = spawn_with_diffs(s, inc, m, bs, P);
+    const V3 o[4] = {r.rx_origin, r.ry_origin, r.rx_direction, r.ry_direction};
+    for (int k = 0; k < 4; ++k) { out12[3 * k] = o[k].x; out12[3 * k + 1] = o[k].y; out12[3 * k + 2] = o[k].z; }
 }
 // lights.rs:7-15 sample_sphere (dormant AreaLight path, kept for its known answer: |p| = 1)
 void orc_sample_sphere(double rnd, double rnd2, double* out3) {

@@ -19,6 +19,7 @@ PT_OK, PT_ERR_INVALID, PT_ERR_NOMEM, PT_ERR_DEVICE, PT_ERR_IO, PT_ERR_UNSUPPORTE
 PT_MAT_LAMBERT, PT_MAT_GLOSSY, PT_MAT_MIRROR, PT_MAT_TRANSPARENT, PT_MAT_GLOSSY_GGX = 0, 1, 2, 3, 4
 PT_BVH_EMPTY = 0x7FFFFFFF
 PT_FLAG_USE_DIFFS, PT_FLAG_NEE, PT_FLAG_DROP_NONFINITE, PT_FLAG_RUSSIAN_ROULETTE = 1, 2, 4, 8
+PT_FLAG_PROPAGATE_DIFFS, PT_FLAG_ROUGHDIFF = 16, 32
 PT_LOAD_GLOSSY, PT_LOAD_TEXTURES, PT_LOAD_SPECULAR, PT_LOAD_GGX = 1, 2, 4, 8
 PT_K_GENERATE, PT_K_EXTEND, PT_K_SHADE, PT_K_SHADOW, PT_K_ACCUMULATE, PT_K_PATH, PT_K_COUNT = 0, 1, 2, 3, 4, 5, 6
 KERNEL_NAMES = ("generate", "extend", "shade", "shadow", "accumulate", "path")
@@ -69,7 +70,7 @@ class pt_render_params(C.Structure):
                 ("x0", C.c_uint32), ("y0", C.c_uint32), ("x1", C.c_uint32), ("y1", C.c_uint32),
                 ("sample_begin", C.c_uint64), ("sample_count", C.c_uint32),
                 ("max_bounces", C.c_uint32), ("flags", C.c_uint32), ("spp_per_batch", C.c_uint32),
-                ("seed", C.c_uint64)]
+                ("seed", C.c_uint64), ("diff_size", C.c_double)]
 
 
 class pt_checkpoint_info(C.Structure):

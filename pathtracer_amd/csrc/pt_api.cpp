@@ -100,14 +100,15 @@ struct Workspace {
     uint32_t cap_slots = 0;   // Lsample entries (all lanes together)
     uint32_t lane_slots = 0;  // path slots per lane
     int n_lanes = 0;
-    bool nee = false;
+    bool nee = false, diffs = false;
     Lane lane[2];
     ptd::Sample3 ls;
     DevBuf jitter;
     uint64_t jitter_cap = 0;
 };
 
-void carve_workspace(Workspace& w, void* base, uint32_t n_slots, uint32_t lane_slots, int n_lanes, bool nee, size_t& total) {
+void carve_workspace(Workspace& w, void* base, uint32_t n_slots, uint32_t lane_slots, int n_lanes, bool nee, bool diffs,
+                     size_t& total) {
     Carver c(base);
     // queues, hit records and the shadow queue are segmented (ptd::kSegs segments); Lsample is per slot
     const uint32_t slots = ptd::kSegs * ptd::seg_size_for(lane_slots);
@@ -119,6 +120,8 @@ void carve_workspace(Workspace& w, void* base, uint32_t n_slots, uint32_t lane_s
             for (int a = 0; a < 3; ++a) ln.q[k].T[a] = c.take<double>(slots);
             ln.q[k].prev_pdf = nee ? c.take<double>(slots) : nullptr;
             ln.q[k].slot = c.take<uint32_t>(slots);
+            ln.q[k].diff = diffs ? c.take<double>((size_t)12 * slots) : nullptr;
+            ln.q[k].diff_stride = slots;
         }
         ln.hits.tri = c.take<uint32_t>(slots);
         ln.hits.t = c.take<double>(slots);
@@ -215,22 +218,24 @@ int upload(DevBuf& b, const T* src, size_t n) {
     return PT_OK;
 }
 
-int ensure_workspace(pt_scene* s, uint32_t slots, uint32_t lane_slots, int n_lanes, bool nee) {
+int ensure_workspace(pt_scene* s, uint32_t slots, uint32_t lane_slots, int n_lanes, bool nee, bool diffs) {
     Workspace& w = s->ws;
-    if (w.buf.p && w.cap_slots >= slots && w.lane_slots >= lane_slots && w.n_lanes >= n_lanes && (w.nee || !nee))
+    if (w.buf.p && w.cap_slots >= slots && w.lane_slots >= lane_slots && w.n_lanes >= n_lanes && (w.nee || !nee) &&
+        (w.diffs || !diffs))
         return PT_OK;
     HIP_TRY(hipDeviceSynchronize());
     w.buf.release();
     w.cap_slots = 0;
     size_t total = 0;
     Workspace probe;
-    carve_workspace(probe, nullptr, slots, lane_slots, n_lanes, nee, total);
+    carve_workspace(probe, nullptr, slots, lane_slots, n_lanes, nee, diffs, total);
     hipError_t e = w.buf.alloc(total);
     if (e != hipSuccess) {
         set_error("workspace allocation of %zu bytes failed: %s", total, hipGetErrorString(e));
         return PT_ERR_NOMEM;
     }
-    carve_workspace(w, w.buf.p, slots, lane_slots, n_lanes, nee, total);
+    carve_workspace(w, w.buf.p, slots, lane_slots, n_lanes, nee, diffs, total);
+    w.diffs = diffs;
     w.cap_slots = slots;
     w.lane_slots = lane_slots;
     w.n_lanes = n_lanes;
@@ -304,6 +309,10 @@ int check_params(const pt_render_params* p) {
     }
     if (p->max_bounces > kMaxBounces) { set_error("max_bounces > %u", kMaxBounces); return PT_ERR_UNSUPPORTED; }
     if ((uint64_t)(p->x1 - p->x0) * (p->y1 - p->y0) > (1ull << 30)) { set_error("tile too large"); return PT_ERR_UNSUPPORTED; }
+    if ((p->flags & PT_FLAG_PROPAGATE_DIFFS) && !std::isfinite(p->diff_size)) {
+        set_error("diff_size is not finite");
+        return PT_ERR_INVALID;
+    }
     return PT_OK;
 }
 
@@ -438,6 +447,7 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
     for (uint32_t i = 0; i < d->n_mats; ++i) {
         const pt_material& m = d->mats[i];
         for (int c = 0; c < 3; ++c) { mats[i].color[c] = (double)m.color[c]; mats[i].emission[c] = (double)m.emission[c]; }
+        mats[i].roughness = (double)m.roughness;
         mats[i].width = m.kind == PT_MAT_GLOSSY_GGX ? (double)m.roughness                 // GGX::new, microfacet.rs:197-199
                                                     : std::fmax((double)m.roughness, 1e-5);  // Beckmann::new, microfacet.rs:125
         mats[i].kind = m.kind;
@@ -646,6 +656,9 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
     const uint32_t tw = P->x1 - P->x0, th = P->y1 - P->y0;
     const uint32_t npix = tw * th;
     const bool nee = (P->flags & PT_FLAG_NEE) != 0 && s->dev.n_lights > 0;
+    // differentials only feed texture filtering: without a texture (or a second vertex) nothing reads them
+    const bool diffs = (P->flags & PT_FLAG_PROPAGATE_DIFFS) && (P->flags & PT_FLAG_USE_DIFFS) && s->n_texs > 0 &&
+                       P->max_bounces > 0;
     // frames in flight per pass: ~16M paths fill the chip many times over and keep launches few
     uint32_t spp = P->spp_per_batch;
     if (spp == 0) spp = std::max<uint32_t>(1u, (1u << 24) / npix);
@@ -655,7 +668,7 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
     // two lanes when a batch has frames to split and enough paths for each half to fill the chip
     const bool two = s->pipeline != 0 && spp >= 2 && (uint64_t)(spp / 2) * npix >= kMinLanePaths;
     const uint32_t lane_spp = two ? spp - spp / 2 : spp;
-    if ((rc = ensure_workspace(s, slots, lane_spp * npix, two ? 2 : 1, nee)) != PT_OK) return rc;
+    if ((rc = ensure_workspace(s, slots, lane_spp * npix, two ? 2 : 1, nee, diffs)) != PT_OK) return rc;
     Workspace& w = s->ws;
     if (two && (rc = ensure_side_stream(s, 2)) != PT_OK) return rc;
     if (w.jitter_cap < P->sample_count) {
@@ -671,7 +684,8 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
 
     // a bounce runs as the fused path kernel where one exists; the node/triangle counters of
     // profiling level 2 live in the extend kernel, so that level keeps the two-kernel form
-    auto can_fuse = [&](uint32_t bounce) { return !stats && ptd::path_fusable(s->dev, bounce); };
+    // (and the differential-carrying shade kernel has no fused form)
+    auto can_fuse = [&](uint32_t bounce) { return !stats && !diffs && ptd::path_fusable(s->dev, bounce); };
     struct LaneRun {  // one lane's share of the batch
         Lane* ln;
         hipStream_t st;
@@ -722,7 +736,8 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
         fr.sample_base = P->sample_begin + b0;
         fr.seed = P->seed;
         fr.max_bounces = P->max_bounces;
-        fr.flags = P->flags;
+        fr.flags = diffs ? P->flags : (P->flags & ~(uint32_t)PT_FLAG_PROPAGATE_DIFFS);
+        fr.diff_size = P->diff_size;
         fr.jitter = w.jitter.as<double>() + (size_t)b0 * 2;
         // the generate stage is fused into the bounce-0 extend and shade kernels (they rebuild the
         // camera ray from the pixel): no primary-ray queue is written or read.

@@ -18,6 +18,7 @@ struct Material {
     double color[3];
     double emission[3];
     double width;  // Beckmann width = max(roughness, 1e-5) (microfacet.rs:125)
+    double roughness;  // as given (main.rs:252 scales the differential spread by it)
     int32_t kind;
     int32_t tex;
     double ior;  // TRANSPARENT
@@ -115,6 +116,10 @@ struct Queue {
     double* T[3];      // path throughput ("accumulated_pdf", main.rs:290)
     double* prev_pdf;  // pdf of the BRDF sample that spawned the ray (NEE/MIS only)
     uint32_t* slot;    // path slot = sample_in_batch * n_tile_pixels + tile_pixel
+    // PT_FLAG_PROPAGATE_DIFFS only (else nullptr): the ray's differential rays, 12 arrays of
+    // diff_stride doubles: rx_origin, ry_origin, rx_direction, ry_direction (ray.rs:9-12)
+    double* diff;
+    uint32_t diff_stride;
 };
 
 struct Sample3 {  // per-slot radiance of the batch ("color_result", main.rs:287), SoA
@@ -174,6 +179,7 @@ struct Frame {  // per-call constants of generate / shade
     uint32_t max_bounces;
     uint32_t flags;
     const double* jitter;  // [n_samples][2] frame jitters, already scaled by the pixel size
+    double diff_size;      // CONFIG.diff_size (PT_FLAG_PROPAGATE_DIFFS)
 };
 
 struct Counters {  // device-side statistics (pt_stats)

@@ -714,12 +714,32 @@ __device__ __forceinline__ void solve2x2(double a00, double a01, double a10, dou
     x0 = r0; x1 = r1;
 }
 
+// The differential rays of a ray (ray.rs:9-12).
+struct RayDiffs {
+    D3 rxo, ryo, rxd, ryd;
+};
+// surface.rs:65-84: where the differential rays meet the tangent plane of the hit.  false (and
+// zeros) when either distance is infinite or NaN, which is what the all-zero differential rays of
+// a Ray::new ray (main.rs:314) give.
+__device__ __forceinline__ bool surface_dp(D3 normal, D3 position, const RayDiffs& rd, D3& dpdx, D3& dpdy) {
+    double dd = dot(normal, position);
+    double tx = -(dot(normal, rd.rxo) - dd) / dot(normal, rd.rxd);
+    double ty = -(dot(normal, rd.ryo) - dd) / dot(normal, rd.ryd);
+    dpdx = dpdy = mk(0., 0., 0.);
+    if (isinf(tx) || tx != tx || isinf(ty) || ty != ty) return false;
+    D3 px = rd.rxo + tx * rd.rxd;
+    D3 py = rd.ryo + ty * rd.ryd;
+    dpdx = px - position;
+    dpdy = py - position;
+    return true;
+}
 // Diffuse colour of a textured Lambertian at a hit: uv interpolation + dpdu/dpdv
-// (triangle_mesh.rs:128-138), ray differentials (surface.rs:59-109), material.rs:100-111.
-// `has_diffs`: the ray carries differentials (primary ray with CONFIG.use_diffs); secondary rays
-// have all-zero differential rays (main.rs:314 Ray::new), which surface.rs:72-80 turns into zeros.
+// (triangle_mesh.rs:128-138), ray differentials (surface.rs:86-109), material.rs:100-111.
+// `has_dp`: dpdx / dpdy hold surface_dp's result for a ray that carries differentials (a primary
+// ray with CONFIG.use_diffs, or any ray under PT_FLAG_PROPAGATE_DIFFS); otherwise the texture
+// derivatives are zero (surface.rs:72-80).
 __device__ D3 textured_color(const Scene& sc, const Material& m, const TriV& tr, uint32_t leaf, D3 o, D3 d,
-                             D3 position, D3 normal, bool has_diffs, D3 rx_dir, D3 ry_dir) {
+                             D3 normal, bool has_dp, D3 dpdx, D3 dpdy) {
     double uv[6];
     if (sc.uvs) {
         const float2* up = sc.uvs + (size_t)leaf * 3;
@@ -740,31 +760,20 @@ __device__ D3 textured_color(const Scene& sc, const Material& m, const TriV& tr,
     double tu = uv[0] * u + uv[2] * v + uv[4] * w;
     double tv = uv[1] * u + uv[3] * v + uv[5] * w;
     double dudx = 0., dvdx = 0., dudy = 0., dvdy = 0.;
-    if (has_diffs) {
+    if (has_dp) {
         D3 dp02 = tr.v0 - tr.v2, dp12 = tr.v1 - tr.v2;
         double duv02x = uv[0] - uv[4], duv02y = uv[1] - uv[5], duv12x = uv[2] - uv[4], duv12y = uv[3] - uv[5];
         double determinant = duv02x * duv12y - duv02y * duv12x;
         double inverse_det = 1. / determinant;
         D3 dpdu = (duv12y * dp02 - duv02y * dp12) * inverse_det;
         D3 dpdv = (-duv12x * dp02 + duv02x * dp12) * inverse_det;
-        // surface.rs:65-84 (rx_origin = ry_origin = eye = o for a primary ray)
-        double dd = dot(normal, position);
-        double tx = -(dot(normal, o) - dd) / dot(normal, rx_dir);
-        double ty = -(dot(normal, o) - dd) / dot(normal, ry_dir);
-        bool bad = isinf(tx) || tx != tx || isinf(ty) || ty != ty;
-        if (!bad) {
-            D3 px = o + tx * rx_dir;
-            D3 py = o + ty * ry_dir;
-            D3 dpdx = px - position;
-            D3 dpdy = py - position;
-            int d0, d1;
-            if (fabs(normal.x) > fabs(normal.y) && fabs(normal.x) > fabs(normal.z)) { d0 = 1; d1 = 2; }
-            else if (fabs(normal.y) > fabs(normal.z)) { d0 = 0; d1 = 2; }
-            else { d0 = 0; d1 = 1; }
-            double a00 = comp(dpdu, d0), a01 = comp(dpdv, d0), a10 = comp(dpdu, d1), a11 = comp(dpdv, d1);
-            solve2x2(a00, a01, a10, a11, comp(dpdx, d0), comp(dpdx, d1), dudx, dvdx);
-            solve2x2(a00, a01, a10, a11, comp(dpdy, d0), comp(dpdy, d1), dudy, dvdy);
-        }
+        int d0, d1;
+        if (fabs(normal.x) > fabs(normal.y) && fabs(normal.x) > fabs(normal.z)) { d0 = 1; d1 = 2; }
+        else if (fabs(normal.y) > fabs(normal.z)) { d0 = 0; d1 = 2; }
+        else { d0 = 0; d1 = 1; }
+        double a00 = comp(dpdu, d0), a01 = comp(dpdv, d0), a10 = comp(dpdu, d1), a11 = comp(dpdv, d1);
+        solve2x2(a00, a01, a10, a11, comp(dpdx, d0), comp(dpdx, d1), dudx, dvdx);
+        solve2x2(a00, a01, a10, a11, comp(dpdy, d0), comp(dpdy, d1), dudy, dvdy);
     }
     return sample_mipmap(sc.texs[m.tex], tu, tv, dudx, dvdx, dudy, dvdy);
 }
@@ -878,14 +887,56 @@ __device__ __forceinline__ double dielectric(double ior, double cos_theta_i) {
 }
 // Mirror (main.rs:178-185) and Transparent (main.rs:117-142; one of its two branches, reflection
 // with probability R from the bounce's first draw).  The radiance passes unchanged either way.
-__device__ __forceinline__ D3 specular_sample(const Material& m, D3 ray_dir, D3 n, double xi1) {
+// `lobe`: 1 = reflected, 2 = refracted (which of reflect_diff / refract_diff spawns the ray).
+__device__ __forceinline__ D3 specular_sample(const Material& m, D3 ray_dir, D3 n, double xi1, int& lobe) {
+    lobe = 1;
     if (m.kind == PT_MAT_MIRROR) return reflect(ray_dir, n);
     double cos_theta = dot(-ray_dir, n);
     double eta = cos_theta < 0. ? m.ior / 1. : 1. / m.ior;  // FresnelDielectric::eta, microfacet.rs:318-326
     double fresnel_r = dielectric(m.ior, cos_theta);
     D3 normal = cos_theta < 0. ? -n : n;
     if (xi1 < fresnel_r) return reflect(ray_dir, normal);
+    lobe = 2;
     return refract(ray_dir, normal, eta);
+}
+// The differential rays of the ray the legacy integrator spawns at a vertex (main.rs:192-281,
+// commented out in the reference): reflect_diff for a Lambertian / Glossy sample (lobe 0) and a
+// specular reflection (lobe 1), refract_diff for a refraction (lobe 2).  dndu = dndv = 0 on every
+// surface the reference builds for a triangle or with Surface::new (surface.rs:40-41), so the
+// dndx / dndy terms, which add only signed zeros, are dropped.
+__device__ RayDiffs spawn_diffs(const Material& m, int lobe, D3 position, D3 surf_normal, D3 dpdx, D3 dpdy, D3 inc_dir,
+                                const RayDiffs& inc, D3 wi, double diff_size, bool roughdiff) {
+    RayDiffs nr;
+    D3 wo = -inc_dir;
+    nr.rxo = position + dpdx;
+    nr.ryo = position + dpdy;
+    if (lobe == 0) {  // main.rs:242-257
+        if (roughdiff && is_glossy(m.kind)) diff_size = diff_size * m.roughness / 0.8;
+        D3 v0;  // vec3.rs:175-184 create_tangent_vectors
+        if (fabs(wi.x) > fabs(wi.y)) v0 = mk(-wi.z, 0., wi.x) / sqrt(wi.x * wi.x + wi.z * wi.z);
+        else v0 = mk(0., wi.z, -wi.y) / sqrt(wi.y * wi.y + wi.z * wi.z);
+        D3 v1 = cross(wi, v0);
+        nr.rxd = normalize(wi + diff_size * v0);
+        nr.ryd = normalize(wi + diff_size * v1);
+        return nr;
+    }
+    double cos_theta = dot(wo, surf_normal);
+    D3 normal = cos_theta < 0. ? -surf_normal : surf_normal;
+    D3 dwodx = -inc.rxd - wo;
+    D3 dwody = -inc.ryd - wo;
+    double dDNdx = dot(dwodx, normal);
+    double dDNdy = dot(dwody, normal);
+    if (lobe == 1) {  // main.rs:258-276
+        nr.rxd = wi - dwodx + 2. * (dDNdx * normal);
+        nr.ryd = wi - dwody + 2. * (dDNdy * normal);
+    } else {  // main.rs:198-221 as written (pbrt-v3's form; its signs are not those of d(refract), kept as the reference has them)
+        double eta = cos_theta < 0. ? m.ior / 1. : 1. / m.ior;
+        double dmudx = (eta - (eta * eta * dot(-wo, normal)) / dot(wi, normal)) * dDNdx;
+        double dmudy = (eta - (eta * eta * dot(-wo, normal)) / dot(wi, normal)) * dDNdy;
+        nr.rxd = wi + eta * dwodx - dmudx * normal;
+        nr.ryd = wi + eta * dwody - dmudy * normal;
+    }
+    return nr;
 }
 // material.rs:9-23 + 37-58
 __device__ __forceinline__ Brdf lambertian_sample(D3 color, D3 n, double xi1, double xi2) {
@@ -954,20 +1005,22 @@ __device__ __forceinline__ void hit_geometry(const Scene& sc, uint32_t leaf, D3 
     mat = ts.mat;
     normal = ld3(ts.n);
 }
+// scene.rs:47-54: the differential rays of the camera ray of `pixel` in frame `s` of the batch
+__device__ __forceinline__ RayDiffs camera_diffs(const Scene& sc, const Frame& fr, D3 eye, uint32_t pixel, uint32_t s) {
+    PixelArgs a = pixel_args(pixel % fr.width, pixel / fr.width, fr.width, fr.height, fr.jitter[2 * s],
+                             fr.jitter[2 * s + 1]);
+    return {eye, eye, camera_dir(sc.cam, a.x + a.ddx, a.y), camera_dir(sc.cam, a.x, a.y + a.ddy)};
+}
 __device__ __forceinline__ D3 diffuse_of(const Scene& sc, const Material& m, uint32_t leaf, D3 o,
                                          D3 d, D3 position, D3 normal, const Frame& fr, bool primary,
                                          uint32_t pixel, uint32_t s) {
     if (m.tex < 0) return ld3(m.color);
     const TriV tr = load_tri(sc, leaf);  // only a textured hit needs the vertices again (uv, dpdu, dpdv)
-    bool has_diffs = primary && (fr.flags & PT_FLAG_USE_DIFFS);
-    D3 rx = mk(0., 0., 0.), ry = rx;
-    if (has_diffs) {  // scene.rs:47-54
-        PixelArgs a = pixel_args(pixel % fr.width, pixel / fr.width, fr.width, fr.height, fr.jitter[2 * s],
-                                 fr.jitter[2 * s + 1]);
-        rx = camera_dir(sc.cam, a.x + a.ddx, a.y);
-        ry = camera_dir(sc.cam, a.x, a.y + a.ddy);
-    }
-    return textured_color(sc, m, tr, leaf, o, d, position, normal, has_diffs, rx, ry);
+    bool has_dp = false;
+    D3 dpdx = mk(0., 0., 0.), dpdy = dpdx;
+    if (primary && (fr.flags & PT_FLAG_USE_DIFFS))
+        has_dp = surface_dp(normal, position, camera_diffs(sc, fr, o, pixel, s), dpdx, dpdy);
+    return textured_color(sc, m, tr, leaf, o, d, normal, has_dp, dpdx, dpdy);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1021,6 +1074,7 @@ struct ShadeOut {
     double n_pdf = 0.;
     D3 s_d, s_c;  // shadow ray direction and the radiance it carries if unoccluded
     double s_tmax = 0.;
+    RayDiffs n_diff;  // DIFFS: the next ray's differential rays
 };
 // the part of a path record the shading needs besides the ray; the fused kernel loads it before
 // it walks the tree, so that the loads' latency is hidden behind the traversal
@@ -1033,7 +1087,10 @@ __device__ __forceinline__ PathRec load_rec(const Queue& in, uint32_t i) {
     if (FIRST) return {i, mk(1., 1., 1.)};
     return {in.slot[i], mk(in.T[0][i], in.T[1][i], in.T[2][i])};
 }
-template <bool FIRST, bool LAST, bool NEE, bool PLAIN, bool FUSED>
+//   DIFFS = PT_FLAG_PROPAGATE_DIFFS (with USE_DIFFS, on a scene with textures): rays carry their
+//           differential rays through the queue (Queue::diff) and every vertex spawns them as the
+//           legacy reflect_diff / refract_diff do.
+template <bool FIRST, bool LAST, bool NEE, bool PLAIN, bool FUSED, bool DIFFS = false>
 __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, uint32_t bounce, const Queue& in,
                                              uint32_t i, PathRec rec, uint32_t leaf, double t_hit, D3 o, D3 d,
                                              const Sample3& ls, ShadeOut& r) {
@@ -1084,7 +1141,25 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
         }
         if (!LAST) {
             D3 diffuse = mk(0., 0., 0.);
-            if (PLAIN) diffuse = ld3(m.color);
+            RayDiffs inc_diff;
+            D3 dpdx = mk(0., 0., 0.), dpdy = dpdx;
+            if (DIFFS) {  // surface.rs:59-84 for the ray's own differentials, at every vertex
+                if (FIRST) {
+                    inc_diff = camera_diffs(sc, fr, o, pixel, s);
+                } else {
+                    const double* q = in.diff + i;
+                    const size_t st = in.diff_stride;
+                    inc_diff.rxo = mk(q[0], q[st], q[2 * st]);
+                    inc_diff.ryo = mk(q[3 * st], q[4 * st], q[5 * st]);
+                    inc_diff.rxd = mk(q[6 * st], q[7 * st], q[8 * st]);
+                    inc_diff.ryd = mk(q[9 * st], q[10 * st], q[11 * st]);
+                }
+                // an analytic primitive's surface is Surface::new (geometry/mod.rs:46,71): no differentials
+                bool has_dp = leaf < PT_PRIM_BASE && surface_dp(normal, position, inc_diff, dpdx, dpdy);
+                if (m.kind == PT_MAT_LAMBERT)
+                    diffuse = m.tex < 0 ? ld3(m.color)
+                                        : textured_color(sc, m, load_tri(sc, leaf), leaf, o, d, normal, has_dp, dpdx, dpdy);
+            } else if (PLAIN) diffuse = ld3(m.color);
             else if (m.kind == PT_MAT_LAMBERT) diffuse = diffuse_of(sc, m, leaf, o, d, position, normal, fr, FIRST, pixel, s);
             if (NEE && sc.n_lights) {
                 double r0, r1;
@@ -1153,9 +1228,10 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
             if (!absorbed) {
                 double xi1, xi2;
                 uniform2(fr.seed, pixel, sample, bounce, STREAM_BRDF, xi1, xi2);
+                int lobe = 0;
                 if (!PLAIN && (m.kind == PT_MAT_MIRROR || m.kind == PT_MAT_TRANSPARENT)) {
                     r.n_T = T;  // specular: radiance passes unchanged
-                    r.n_d = specular_sample(m, d, normal, xi1);
+                    r.n_d = specular_sample(m, d, normal, xi1, lobe);
                     r.n_pdf = -1.;
                 } else {
                     Brdf bs = (!PLAIN && is_glossy(m.kind)) ? glossy_sample(m.width, ld3(m.color), d, normal, xi1, xi2, m.kind == PT_MAT_GLOSSY_GGX)
@@ -1166,6 +1242,9 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
                 }
                 if (luminance != 1.) r.n_T = r.n_T / luminance;
                 r.n_o = position;  // main.rs:314
+                if (DIFFS)
+                    r.n_diff = spawn_diffs(m, lobe, position, normal, dpdx, dpdy, d, inc_diff, r.n_d, fr.diff_size,
+                                           (fr.flags & PT_FLAG_ROUGHDIFF) != 0);
                 r.alive = true;
             }
         }
@@ -1178,8 +1257,15 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
     }
 }
 
-template <bool NEE>
+template <bool NEE, bool DIFFS = false>
 __device__ __forceinline__ void push_path(const Queue& out, uint32_t pos, const ShadeOut& r) {
+    if (DIFFS) {
+        double* q = out.diff + pos;
+        const size_t st = out.diff_stride;
+        const D3 v[4] = {r.n_diff.rxo, r.n_diff.ryo, r.n_diff.rxd, r.n_diff.ryd};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { q[3 * k * st] = v[k].x; q[(3 * k + 1) * st] = v[k].y; q[(3 * k + 2) * st] = v[k].z; }
+    }
     out.o[0][pos] = r.n_o.x; out.o[1][pos] = r.n_o.y; out.o[2][pos] = r.n_o.z;
     out.d[0][pos] = r.n_d.x; out.d[1][pos] = r.n_d.y; out.d[2][pos] = r.n_d.z;
     out.T[0][pos] = r.n_T.x; out.T[1][pos] = r.n_T.y; out.T[2][pos] = r.n_T.z;
@@ -1195,7 +1281,7 @@ __device__ __forceinline__ void push_shadow(const ShadowQueue& sq, uint32_t spos
 }
 
 // shade: one lane per live path.
-template <bool FIRST, bool LAST, bool NEE, bool PLAIN>
+template <bool FIRST, bool LAST, bool NEE, bool PLAIN, bool DIFFS = false>
 __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t bounce, Queue in, Hits hits,
                                                   Live live, Queue out, Push out_push, ShadowQueue sq, Push sq_push,
                                                   Sample3 ls) {
@@ -1212,12 +1298,12 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
         uint32_t leaf = hits.tri[i];
         // the hit distance is only needed (and only loaded) where the vertex is shaded in full
         double t = (leaf != PT_MISS && (!LAST || NEE)) ? hits.t[i] : 0.;
-        shade_vertex<FIRST, LAST, NEE, PLAIN, false>(sc, fr, bounce, in, i, load_rec<FIRST>(in, i), leaf, t, mk(0., 0., 0.),
-                                                     mk(0., 0., 0.), ls, r);
+        shade_vertex<FIRST, LAST, NEE, PLAIN, false, DIFFS>(sc, fr, bounce, in, i, load_rec<FIRST>(in, i), leaf, t,
+                                                            mk(0., 0., 0.), mk(0., 0., 0.), ls, r);
     }
     if (LAST) return;  // nothing continues
     uint32_t pos = region * out_push.seg_size + compact_slot(r.alive, out_push.counts + region * kCtrStride, lds_a);
-    if (r.alive) push_path<NEE>(out, pos, r);
+    if (r.alive) push_path<NEE, DIFFS>(out, pos, r);
     if (NEE) {
         uint32_t spos = region * sq_push.seg_size + compact_slot(r.shadow, sq_push.counts + region * kCtrStride, lds_b);
         if (r.shadow) push_shadow(sq, spos, r);
@@ -1348,7 +1434,8 @@ __global__ void k_sample_brdf(Scene sc, Frame fr, uint32_t bounce, const double*
     double xi1, xi2;
     uniform2(fr.seed, pixel, fr.sample_base, bounce, STREAM_BRDF, xi1, xi2);
     Brdf bs;
-    if (m.kind == PT_MAT_MIRROR || m.kind == PT_MAT_TRANSPARENT) bs = {mk(1., 1., 1.), specular_sample(m, d, normal, xi1), -1.};  // pdf < 0: specular
+    int lobe;
+    if (m.kind == PT_MAT_MIRROR || m.kind == PT_MAT_TRANSPARENT) bs = {mk(1., 1., 1.), specular_sample(m, d, normal, xi1, lobe), -1.};  // pdf < 0: specular
     else if (is_glossy(m.kind)) bs = glossy_sample(m.width, ld3(m.color), d, normal, xi1, xi2, m.kind == PT_MAT_GLOSSY_GGX);
     else bs = lambertian_sample(diffuse, normal, xi1, xi2);
     D3 le = m.kind != PT_MAT_LAMBERT ? mk(0., 0., 0.) : ld3(m.emission);
@@ -1425,7 +1512,10 @@ template <bool FIRST, bool LAST>
 static void launch_shade_t(bool nee, dim3 g, dim3 b, hipStream_t st, const Scene& sc, const Frame& fr, uint32_t bounce,
                            Queue in, Hits hits, Live live, Queue out, Push out_push, ShadowQueue sq, Push sq_push,
                            Sample3 ls) {
-    if (sc.plain) {
+    if ((fr.flags & PT_FLAG_PROPAGATE_DIFFS) && !sc.plain) {  // the host sets the flag only where it has an effect
+        if (nee) hipLaunchKernelGGL((k_shade<FIRST, LAST, true, false, true>), g, b, 0, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls);
+        else hipLaunchKernelGGL((k_shade<FIRST, LAST, false, false, true>), g, b, 0, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls);
+    } else if (sc.plain) {
         if (nee) hipLaunchKernelGGL((k_shade<FIRST, LAST, true, true>), g, b, 0, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls);
         else hipLaunchKernelGGL((k_shade<FIRST, LAST, false, true>), g, b, 0, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls);
     } else {

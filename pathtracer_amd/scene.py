@@ -64,6 +64,9 @@ class Config:
     nee: bool = False
     drop_nonfinite: bool = False
     russian_roulette: bool = False  # legacy integrator main.rs:85-93
+    propagate_diffs: bool = False   # legacy reflect_diff / refract_diff, main.rs:192-281 (§8f N3)
+    diff_size: float = 0.0          # --diff (main.rs:348)
+    roughdiff: bool = False         # -p (main.rs:351)
     spp_per_batch: int = 0
 
     @property
@@ -84,6 +87,10 @@ class Config:
             f |= L.PT_FLAG_DROP_NONFINITE
         if self.russian_roulette:
             f |= L.PT_FLAG_RUSSIAN_ROULETTE
+        if self.propagate_diffs:
+            f |= L.PT_FLAG_PROPAGATE_DIFFS
+        if self.roughdiff:
+            f |= L.PT_FLAG_ROUGHDIFF
         return f
 
     def params(self, sample_begin: int, sample_count: int, tile=None) -> L.pt_render_params:
@@ -96,6 +103,7 @@ class Config:
         p.flags = self.flags()
         p.spp_per_batch = self.spp_per_batch
         p.seed = self.seed
+        p.diff_size = self.diff_size
         return p
 
 

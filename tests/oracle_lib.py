@@ -58,6 +58,8 @@ lib.orc_conductor.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, _d
 lib.orc_conductor.restype = None
 lib.orc_fresnel_dielectric.argtypes = [C.c_double, C.c_double]
 lib.orc_fresnel_dielectric.restype = C.c_double
+lib.orc_spawn_diffs.argtypes = [_dp, _dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_uint32, _dp]
+lib.orc_spawn_diffs.restype = None
 lib.orc_refract.argtypes = [_dp, _dp, C.c_double, _dp]
 lib.orc_refract.restype = None
 lib.orc_normalize.argtypes = [_dp, _dp]
@@ -218,6 +220,15 @@ def rotate_to(v, n):
 
 def sample_sphere(r1, r2):
     return vec3_fn(lib.orc_sample_sphere, r1, r2)
+
+
+def spawn_diffs(position, normal, dpdx, dpdy, inc_dir, inc_rx_dir, inc_ry_dir, wi, kind, lobe, roughness=0.0, ior=1.0,
+                diff_size=0.0, flags=0):
+    """main.rs:192-281 reflect_diff / refract_diff: (rx_origin, ry_origin, rx_direction, ry_direction)."""
+    vin = np.ascontiguousarray(np.concatenate([position, normal, dpdx, dpdy, inc_dir, inc_rx_dir, inc_ry_dir]), np.float64)
+    out = (C.c_double * 12)()
+    lib.orc_spawn_diffs(vin.ctypes.data_as(_dp), _d3(wi), kind, lobe, roughness, ior, diff_size, flags, out)
+    return np.array(out[:]).reshape(4, 3)
 
 
 def ggx_D(roughness, m, n):
