@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpt_hip.so")
+LIB_PATH = os.environ.get("PT_LIB_PATH") or os.path.join(_HERE, "lib", "libpt_hip.so")  # PT_LIB_PATH: tuning builds
 
 PT_MISS = 0xFFFFFFFF
 PT_PRIM_BASE = 0xF0000000

@@ -154,7 +154,7 @@ struct pt_scene {
     std::vector<uint32_t> order;
     uint32_t depth = 0;
     ptd::Scene dev{};
-    DevBuf d_nodes, d_tris, d_uvs, d_leaf_of, d_mats, d_texs, d_lights, d_prims, d_tri_shade, d_eye_nodes, d_eye_tris, d_ctr;
+    DevBuf d_nodes, d_tris, d_uvs, d_leaf_of, d_mats, d_texs, d_lights, d_emissive, d_prims, d_tri_shade, d_eye_nodes, d_eye_tris, d_ctr;
     std::vector<DevBuf*> d_texels;
     Workspace ws;
     std::mutex mu;
@@ -477,11 +477,13 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
 
     // ---- lights for NEE: emissive triangles in global id order, area CDF
     std::vector<ptd::Light> lights;
+    std::vector<uint32_t> emissive;  // every triangle whose hit adds radiance (leaf order), for the last-bounce cull
     double acc = 0.;
     for (uint32_t g = 0; g < d->n_tris; ++g) {
         const ptd::Material& m = mats[d->tri_material ? d->tri_material[g] : 0];
         if (m.kind != PT_MAT_LAMBERT) continue;  // only Lambertian surfaces emit (microfacet.rs:33-35; legacy specular branches)
         if (m.emission[0] == 0. && m.emission[1] == 0. && m.emission[2] == 0.) continue;
+        emissive.push_back(leaf_of[g]);
         H3 v[3];
         for (int k = 0; k < 3; ++k) {
             const float* p = d->verts + 3 * (size_t)d->tris[3 * g + k];
@@ -523,6 +525,12 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
         L.sphere = 1;
         lights.push_back(L);
     }
+    bool emissive_prim = false;
+    for (uint32_t k = 0; k < d->n_prims; ++k) {
+        const ptd::Material& m = mats[d->prims[k].material];
+        if (m.kind == PT_MAT_LAMBERT && (m.emission[0] != 0. || m.emission[1] != 0. || m.emission[2] != 0.)) emissive_prim = true;
+    }
+    if ((rc = upload(s->d_emissive, emissive.data(), emissive.size())) != PT_OK) return rc;
     if ((rc = upload(s->d_lights, lights.data(), lights.size())) != PT_OK) return rc;
     if ((rc = upload(s->d_prims, prims.data(), prims.size())) != PT_OK) return rc;
 
@@ -537,6 +545,13 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
     dv.mats = s->d_mats.as<ptd::Material>();
     dv.texs = s->d_texs.as<ptd::Texture>();
     dv.lights = s->d_lights.as<ptd::Light>();
+    dv.emissive = s->d_emissive.as<uint32_t>();
+    dv.n_emissive = (uint32_t)emissive.size();
+    // last-bounce cull (pt_kernels.hip may_reach_emitter): needs a black background and emitters that
+    // are a few triangles; PT_LIGHT_CULL=0 switches it off (tests render both ways)
+    dv.cull_last = !emissive_prim && emissive.size() <= ptd::kMaxCullEmitters && d->background[0] == 0. &&
+                   d->background[1] == 0. && d->background[2] == 0.;
+    if (const char* e = getenv("PT_LIGHT_CULL")) dv.cull_last = dv.cull_last && atoi(e) != 0;
     dv.prims = s->d_prims.as<ptd::Prim>();
     dv.n_prims = d->n_prims;
     dv.n_nodes = d->n_tris ? (uint32_t)s->nodes.size() : 0u;

@@ -73,6 +73,7 @@ struct EyeTri {
     uint32_t pad;
 };
 constexpr uint32_t kEyeTableMaxTris = 1u << 16;
+constexpr uint32_t kMaxCullEmitters = 8;  // more emitters than this and testing them all costs more than it saves
 
 struct Light {  // one emissive triangle, or (sphere != 0) an emissive sphere: v0 = centre, v1[0] = radius (NEE)
     double v0[3], v1[3], v2[3];
@@ -94,6 +95,12 @@ struct Scene {
     const Material* mats;
     const Texture* texs;
     const Light* lights;
+    // Emissive triangles (leaf-order indices), for the last-bounce cull: a ray spawned at the
+    // second-to-last vertex can only add radiance if it hits one of them (black background), so one
+    // that passes none of their triangle tests is dropped instead of being queued and traced.
+    const uint32_t* emissive;
+    uint32_t n_emissive;
+    uint32_t cull_last;  // the cull applies to this scene (black background, few emitters, no emissive sphere)
     const Prim* prims;  // tested against every ray before the tree is walked; hit id PT_PRIM_BASE + k
     uint32_t n_prims;
     uint32_t n_nodes, n_tris, n_lights, bvh_depth;

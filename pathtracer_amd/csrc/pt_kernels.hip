@@ -1057,6 +1057,22 @@ __device__ __forceinline__ uint32_t compact_wave(bool alive, uint32_t* counter) 
     return __shfl(base, 0) + lane_prefix;
 }
 
+// Last-bounce cull.  The ray spawned at the second-to-last vertex is traced only to add
+// T * Le of its closest hit (main.rs:307) or T * background (main.rs:299).  With a black background
+// that is +-0 - which the accumulation ignores - unless the closest hit is an emitter, and it cannot
+// be one if the ray fails the triangle test of every emitter.  Such a ray is dropped here, at its
+// producer: it is never queued, read back or traced, and the image is bit-identical.  Non-finite
+// rays and throughputs are kept (NaN * 0 is not 0; the reference accumulates those).
+__device__ __forceinline__ bool finite3(D3 a) { return (a.x - a.x == 0.) && (a.y - a.y == 0.) && (a.z - a.z == 0.); }
+__device__ __forceinline__ bool may_reach_emitter(const Scene& sc, D3 o, D3 d, D3 T) {
+    if (!(finite3(o) && finite3(d) && finite3(T))) return true;
+    for (uint32_t k = 0; k < sc.n_emissive; ++k) {
+        double t, v, w;
+        if (tri_test(load_tri(sc, sc.emissive[k]), o, d, 1e-5, 1.7976931348623157e308, t, v, w)) return true;
+    }
+    return false;
+}
+
 // The shading of one path vertex (main.rs:292-315), shared by the shade kernel and the fused path
 // kernel.
 //   FIRST = bounce 0: queue index == slot, throughput == 1, and the camera ray is recomputed from
@@ -1246,6 +1262,7 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
                     r.n_diff = spawn_diffs(m, lobe, position, normal, dpdx, dpdy, d, inc_diff, r.n_d, fr.diff_size,
                                            (fr.flags & PT_FLAG_ROUGHDIFF) != 0);
                 r.alive = true;
+                if (sc.cull_last && bounce + 1 == fr.max_bounces) r.alive = may_reach_emitter(sc, r.n_o, r.n_d, r.n_T);
             }
         }
     }
@@ -1320,7 +1337,10 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
 // 64 -> 9.38, 128 -> 11.09, 256 -> 10.93, 512 -> 9.90 Gsamples/s: one-wave workgroups are bound by
 // workgroup dispatch when every wave is short), one wave for deep trees (waves differ 10x in length;
 // LDS and registers are released per wave).
-template <int DEPTH> struct PathBlock { static constexpr int value = DEPTH <= 8 ? 128 : 64; };
+#ifndef PT_PATH_BLOCK_DEEP
+#define PT_PATH_BLOCK_DEEP 64
+#endif
+template <int DEPTH> struct PathBlock { static constexpr int value = DEPTH <= 8 ? 128 : PT_PATH_BLOCK_DEEP; };
 template <int DEPTH, bool FIRST, bool LAST, bool NEE, bool PLAIN>
 __global__ __launch_bounds__(PathBlock<DEPTH>::value) void k_path(Scene sc, Frame fr, uint32_t bounce, Queue in, Live live, Queue out,
                                                  Push out_push, ShadowQueue sq, Push sq_push, Sample3 ls,

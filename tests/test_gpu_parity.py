@@ -397,3 +397,42 @@ def test_eye_tables_are_bitwise_identical(gpu, monkeypatch, name):
     for cfg in (pt.Config(width=211, height=97, samples_pr_pixel=3, bounces=2, seed=5, drop_nonfinite=True),
                 pt.Config(dim=64, samples_pr_pixel=2, bounces=0, seed=1, nee=True, drop_nonfinite=True)):
         assert general.render(cfg).tobytes() == tables.render(cfg).tobytes(), (name, cfg)
+
+
+@pytest.mark.parametrize("name", ["CornellBox", "Test", "glossy_planes", "heightfield40"])
+def test_last_bounce_emitter_cull_is_bit_identical(gpu, monkeypatch, name):
+    # a ray spawned at the second-to-last vertex that passes no emitter's triangle test is dropped at
+    # its producer instead of being queued and traced (black background): same bits, fewer rays.
+    # glossy_planes' alpha = 1e-5 strips make NaN / inf throughputs, which the cull must keep.
+    if name == "heightfield40":
+        from pathtracer_amd.synthetic import heightfield_box
+        data = heightfield_box(cells=40)
+    else:
+        data = pt.scene_data(name, textures=True, specular=True) if name == "Test" else pt.scene_data(name, glossy=name == "glossy_planes")
+    monkeypatch.setenv("PT_LIGHT_CULL", "0")
+    full = pt.Scene(data, gpu)
+    monkeypatch.delenv("PT_LIGHT_CULL")
+    cull = pt.Scene(data, gpu)
+    for cfg in (pt.Config(width=160, height=90, samples_pr_pixel=4, bounces=2, seed=5),
+                pt.Config(dim=72, samples_pr_pixel=3, bounces=1, seed=2, nee=True),
+                pt.Config(dim=64, samples_pr_pixel=2, bounces=5, seed=9, nee=True, russian_roulette=True),
+                pt.Config(dim=64, samples_pr_pixel=2, bounces=0, seed=1)):
+        full.reset_stats(); cull.reset_stats()
+        a, b = full.render(cfg), cull.render(cfg)
+        assert a.tobytes() == b.tobytes(), (name, cfg)
+        if cfg.bounces:
+            assert cull.stats()["rays"] < full.stats()["rays"]
+    # the unfused two-kernel form culls the same way
+    monkeypatch.setenv("PT_FUSE", "0")
+    unfused = pt.Scene(data, gpu)
+    monkeypatch.delenv("PT_FUSE")
+    cfg = pt.Config(dim=80, samples_pr_pixel=3, bounces=3, seed=4)
+    assert unfused.render(cfg).tobytes() == full.render(cfg).tobytes()
+    # a scene with a bright background cannot cull: every miss adds radiance
+    import copy
+    lit = copy.copy(data)
+    lit.background = (0.25, 0.5, 1.0)
+    sl, ol = pt.Scene(lit, gpu), O.OracleScene(lit)
+    cfg = pt.Config(dim=48, samples_pr_pixel=2, bounces=2, seed=3, drop_nonfinite=True)
+    img, ref = sl.render(cfg), ol.render(pt.Config(dim=48, samples_pr_pixel=2, bounces=2, seed=3, drop_nonfinite=True))
+    assert (np.abs(img - ref) > 1e-6 * np.maximum(1.0, np.abs(ref))).mean() < 1e-2
