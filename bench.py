@@ -29,9 +29,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--spp", type=int, default=8, help="frames per step")
+    ap.add_argument("--spp", type=int, default=32, help="frames per step")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default="CornellBox", help="models/<scene>.obj, or 'heightfield' (SURVEY config 5)")

@@ -674,16 +674,24 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
     // differentials only feed texture filtering: without a texture (or a second vertex) nothing reads them
     const bool diffs = (P->flags & PT_FLAG_PROPAGATE_DIFFS) && (P->flags & PT_FLAG_USE_DIFFS) && s->n_texs > 0 &&
                        P->max_bounces > 0;
-    // frames in flight per pass: ~16M paths fill the chip many times over and keep launches few
+    // Frames in flight per pass.  Every launch ends in a tail that does not shrink with the batch (the
+    // longest rays of the 10M-triangle scene take ~0.4 ms on their own; measured 0.30 + 0.47 ms per
+    // frame for its primary kernel at 4K), so batches are large: ~64M paths by default (~13 GB of
+    // queues out of 288), halved while the allocation does not fit.
     uint32_t spp = P->spp_per_batch;
-    if (spp == 0) spp = std::max<uint32_t>(1u, (1u << 24) / npix);
+    if (spp == 0) spp = std::max<uint32_t>(1u, (1u << 26) / npix);
     spp = std::min(spp, P->sample_count);
     spp = std::min<uint32_t>(spp, std::max<uint32_t>(1u, (1u << 30) / npix));
-    const uint32_t slots = spp * npix;
-    // two lanes when a batch has frames to split and enough paths for each half to fill the chip
-    const bool two = s->pipeline != 0 && spp >= 2 && (uint64_t)(spp / 2) * npix >= kMinLanePaths;
-    const uint32_t lane_spp = two ? spp - spp / 2 : spp;
-    if ((rc = ensure_workspace(s, slots, lane_spp * npix, two ? 2 : 1, nee, diffs)) != PT_OK) return rc;
+    bool two = false;
+    for (;;) {
+        // two lanes when a batch has frames to split and enough paths for each half to fill the chip
+        two = s->pipeline != 0 && spp >= 2 && (uint64_t)(spp / 2) * npix >= kMinLanePaths;
+        const uint32_t lane_spp = two ? spp - spp / 2 : spp;
+        rc = ensure_workspace(s, spp * npix, lane_spp * npix, two ? 2 : 1, nee, diffs);
+        if (rc != PT_ERR_NOMEM || spp == 1 || P->spp_per_batch != 0) break;
+        spp = (spp + 1) / 2;
+    }
+    if (rc != PT_OK) return rc;
     Workspace& w = s->ws;
     if (two && (rc = ensure_side_stream(s, 2)) != PT_OK) return rc;
     if (w.jitter_cap < P->sample_count) {
