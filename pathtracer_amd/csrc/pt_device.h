@@ -165,6 +165,8 @@ struct Live {                 // which entries of a queue are live
     uint32_t n;               // dense: live count; segmented: kSegs * seg_size (index range)
     uint32_t* cursors;        // segmented, optional: kSegs work cursors (zeroed by the host) from which
                               // persistent waves claim ranges of entries; nullptr = one range per wave
+    uint32_t sparse;          // segmented: few entries are live (the queue after the last-bounce cull), so the
+                              // launch is a small grid whose workgroups enumerate the live blocks themselves
 };
 struct Push {                 // where survivors are appended
     uint32_t* counts;         // kSegs counters, zeroed by the host before the launch

@@ -495,6 +495,29 @@ __device__ __forceinline__ uint32_t live_end(const Live& lv, uint32_t i0) {
     uint32_t seg = i0 / lv.seg_size;
     return seg * lv.seg_size + min(lv.counts[seg * kCtrStride], lv.seg_size);
 }
+// Logical block `blk` (of BLOCK entries) of a sparsely filled segmented queue -> its entry range;
+// false past the last live block.  Every wave works it out for itself: lane k takes segment k's
+// count (kSegs == 64), a wave prefix sum gives the first block of each segment, a ballot the segment.
+template <int BLOCK>
+__device__ __forceinline__ bool sparse_block(const Live& lv, uint32_t blk, uint32_t& begin, uint32_t& end) {
+    static_assert(kSegs == 64, "one segment per lane");
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t cnt = min(lv.counts[lane * kCtrStride], lv.seg_size);
+    const uint32_t nb = (cnt + BLOCK - 1) / BLOCK;
+    uint32_t pre = nb;  // inclusive prefix
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t v = __shfl_up(pre, d);
+        if (lane >= (uint32_t)d) pre += v;
+    }
+    const unsigned long long m = __ballot(pre > blk);
+    if (!m) return false;
+    const int seg = __ffsll((long long)m) - 1;
+    const uint32_t first = __shfl(pre - nb, seg), seg_cnt = __shfl(cnt, seg);
+    begin = seg * lv.seg_size + (blk - first) * BLOCK;
+    end = min(begin + BLOCK, seg * lv.seg_size + seg_cnt);
+    return true;
+}
 __device__ __forceinline__ unsigned long long live_total(const Live& lv) {
     if (!lv.counts) return lv.n;
     unsigned long long t = 0;
@@ -1304,6 +1327,19 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
                                                   Sample3 ls) {
     __shared__ uint32_t lds_a[kBlock / 64 + 1];
     __shared__ uint32_t lds_b[kBlock / 64 + 1];
+    if (LAST && !FIRST && live.sparse) {  // few live entries: this small grid enumerates the live blocks
+        for (uint32_t blk = blockIdx.x;; blk += gridDim.x) {
+            uint32_t begin, end;
+            if (!sparse_block<kBlock>(live, blk, begin, end)) return;
+            const uint32_t i = begin + threadIdx.x;
+            if (i >= end) continue;
+            ShadeOut r;
+            uint32_t leaf = hits.tri[i];
+            double t = (leaf != PT_MISS && NEE) ? hits.t[i] : 0.;
+            shade_vertex<FIRST, LAST, NEE, PLAIN, false, DIFFS>(sc, fr, bounce, in, i, load_rec<FIRST>(in, i), leaf, t,
+                                                                mk(0., 0., 0.), mk(0., 0., 0.), ls, r);
+        }
+    }
     if (blockIdx.x * kBlock >= live.n) return;
     uint32_t n = live_end(live, blockIdx.x * kBlock);
     if (blockIdx.x * kBlock >= n) return;  // whole block idle
@@ -1350,38 +1386,44 @@ __global__ __launch_bounds__(PathBlock<DEPTH>::value) void k_path(Scene sc, Fram
     __shared__ uint32_t lds_a[kPathBlock / 64 + 1];
     __shared__ uint32_t lds_b[kPathBlock / 64 + 1];
     if (ctr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->rays, live_total(live));
-    uint32_t begin, end;
-    if (live.counts) {
-        begin = blockIdx.x * kPathBlock;
-        if (begin >= live.n) return;
-        end = min(begin + kPathBlock, live_end(live, begin));
-    } else {
-        if (blockIdx.x >= trav_blocks(live.n, kPathBlock)) return;
-        begin = xcd_block(blockIdx.x, kChunkRays / kPathBlock) * kPathBlock;
-        end = min(begin + kPathBlock, live.n);
-    }
-    if (begin >= end) return;
-    const uint32_t i = begin + threadIdx.x;
     ShadeOut r;
     r.n_o = r.n_d = r.n_T = r.s_d = r.s_c = mk(0., 0., 0.);
-    if (i < end) {
-        D3 o, d;
-        if (FIRST) {
-            uint32_t s = i / fr.n_tile_pixels, p = i - s * fr.n_tile_pixels;
-            uint32_t ty = p / fr.tile_w, tx = p - ty * fr.tile_w;
-            PixelArgs a = pixel_args(fr.x0 + tx, fr.y0 + ty, fr.width, fr.height, fr.jitter[2 * s], fr.jitter[2 * s + 1]);
-            o = ld3(sc.cam.eye);
-            d = camera_dir(sc.cam, a.x, a.y);
+    const bool sparse = LAST && !FIRST && live.counts && live.sparse;
+    for (uint32_t blk = blockIdx.x;; blk += gridDim.x) {  // one pass, except over a sparse queue
+        uint32_t begin, end;
+        if (sparse) {  // few live entries: this small grid enumerates the live blocks
+            if (!sparse_block<kPathBlock>(live, blk, begin, end)) return;
+        } else if (live.counts) {
+            begin = blk * kPathBlock;
+            if (begin >= live.n) return;
+            end = min(begin + kPathBlock, live_end(live, begin));
         } else {
-            o = mk(in.o[0][i], in.o[1][i], in.o[2][i]);
-            d = mk(in.d[0][i], in.d[1][i], in.d[2][i]);
+            if (blk >= trav_blocks(live.n, kPathBlock)) return;
+            begin = xcd_block(blk, kChunkRays / kPathBlock) * kPathBlock;
+            end = min(begin + kPathBlock, live.n);
         }
-        const PathRec rec = load_rec<FIRST>(in, i);  // in flight while the tree is walked
-        double t = 1.7976931348623157e308;  // ray.rs:22 f64::MAX; t_min = 1e-5 (ray.rs:21)
-        uint32_t nn = 0, nt = 0;
-        uint32_t leaf = (FIRST && sc.eye_nodes) ? traverse_eye<DEPTH, kPathBlock>(sc, d, 1e-5, t, stack + threadIdx.x)
-                                                : traverse<DEPTH, false, false, kPathBlock>(sc, o, d, 1e-5, t, stack + threadIdx.x, nn, nt);
-        shade_vertex<FIRST, LAST, NEE, PLAIN, true>(sc, fr, bounce, in, i, rec, leaf, t, o, d, ls, r);
+        if (begin >= end) return;
+        const uint32_t i = begin + threadIdx.x;
+        if (i < end) {
+            D3 o, d;
+            if (FIRST) {
+                uint32_t s = i / fr.n_tile_pixels, p = i - s * fr.n_tile_pixels;
+                uint32_t ty = p / fr.tile_w, tx = p - ty * fr.tile_w;
+                PixelArgs a = pixel_args(fr.x0 + tx, fr.y0 + ty, fr.width, fr.height, fr.jitter[2 * s], fr.jitter[2 * s + 1]);
+                o = ld3(sc.cam.eye);
+                d = camera_dir(sc.cam, a.x, a.y);
+            } else {
+                o = mk(in.o[0][i], in.o[1][i], in.o[2][i]);
+                d = mk(in.d[0][i], in.d[1][i], in.d[2][i]);
+            }
+            const PathRec rec = load_rec<FIRST>(in, i);  // in flight while the tree is walked
+            double t = 1.7976931348623157e308;  // ray.rs:22 f64::MAX; t_min = 1e-5 (ray.rs:21)
+            uint32_t nn = 0, nt = 0;
+            uint32_t leaf = (FIRST && sc.eye_nodes) ? traverse_eye<DEPTH, kPathBlock>(sc, d, 1e-5, t, stack + threadIdx.x)
+                                                    : traverse<DEPTH, false, false, kPathBlock>(sc, o, d, 1e-5, t, stack + threadIdx.x, nn, nt);
+            shade_vertex<FIRST, LAST, NEE, PLAIN, true>(sc, fr, bounce, in, i, rec, leaf, t, o, d, ls, r);
+        }
+        if (!sparse) break;
     }
     if (LAST) return;  // nothing continues
     const uint32_t region = blockIdx.x % kSegs;
@@ -1549,6 +1591,10 @@ void launch_shade(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, H
     bool nee = (fr.flags & PT_FLAG_NEE) != 0 && sc.n_lights > 0;
     bool first = bounce == 0, last = bounce >= fr.max_bounces;
     dim3 g(blocks_for(live.n)), b(kBlock);
+    if (last && !first && live.counts && sc.cull_last) {  // the queue after the cull: a few percent full
+        live.sparse = 1;
+        g.x = std::min(g.x, sc.n_cu * 8u);
+    }
     if (first && last) launch_shade_t<true, true>(nee, g, b, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls);
     else if (first) launch_shade_t<true, false>(nee, g, b, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls);
     else if (last) launch_shade_t<false, true>(nee, g, b, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls);
@@ -1580,6 +1626,10 @@ bool launch_path(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, Li
     bool first = bounce == 0, last = bounce >= fr.max_bounces;
     const uint32_t kPathBlock = sc.bvh_depth <= 8 ? PathBlock<8>::value : PathBlock<32>::value;
     dim3 g(live.counts ? (live.n + kPathBlock - 1) / kPathBlock : trav_blocks(live.n, kPathBlock)), b(kPathBlock);
+    if (last && !first && live.counts && sc.cull_last) {  // the queue after the cull: a few percent full
+        live.sparse = 1;
+        g.x = std::min(g.x, sc.n_cu * 8u);
+    }
     #define PT_PATH(D, F, L) launch_path_t<D, F, L>(nee, g, b, st, sc, fr, bounce, in, live, out, out_push, sq, sq_push, ls, ctr)
     if (sc.bvh_depth <= 8) {
         if (first && last) PT_PATH(8, true, true);
