@@ -93,6 +93,7 @@ struct Lane {
     ptd::Hits hits;
     ptd::ShadowQueue sq;
     uint32_t* counters = nullptr;
+    unsigned long long* lit = nullptr;  // Sample3::lit of this lane's slots
 };
 
 struct Workspace {
@@ -136,7 +137,9 @@ void carve_workspace(Workspace& w, void* base, uint32_t n_slots, uint32_t lane_s
         }
         ln.counters = c.take<uint32_t>(kCounterWords);
     }
-    for (int a = 0; a < 3; ++a) w.ls.c[a] = c.take<double>(n_slots);
+    w.ls.c = c.take<double>((size_t)3 * n_slots);
+    for (int l = 0; l < n_lanes; ++l) w.lane[l].lit = c.take<unsigned long long>(((size_t)lane_slots + 63) / 64);
+    w.ls.lit = w.lane[0].lit;
     total = c.off;
 }
 
@@ -775,7 +778,8 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
             r.fr.n_samples = s1 - s0;
             r.fr.sample_base = fr.sample_base + s0;
             r.fr.jitter = fr.jitter + (size_t)s0 * 2;
-            for (int a = 0; a < 3; ++a) r.ls.c[a] = w.ls.c[a] + (size_t)s0 * npix;
+            r.ls.c = w.ls.c + (size_t)3 * s0 * npix;
+            r.ls.lit = w.lane[l].lit;
             r.n_max = (s1 - s0) * npix;
             r.seg = ptd::seg_size_for(r.n_max);  // <= the size the lane was carved for
             r.cap = ptd::kSegs * r.seg;
@@ -810,7 +814,7 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
         }
         {
             Timer t(s, st, PT_K_ACCUMULATE);
-            ptd::launch_accumulate(fr, w.ls, accum_dev, st);
+            ptd::launch_accumulate(fr, w.ls, n_run == 2 ? w.lane[1].lit : nullptr, run[0].fr.n_samples, accum_dev, st);
         }
         HIP_TRY(hipGetLastError());
     }

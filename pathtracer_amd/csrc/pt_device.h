@@ -129,8 +129,15 @@ struct Queue {
     uint32_t diff_stride;
 };
 
-struct Sample3 {  // per-slot radiance of the batch ("color_result", main.rs:287), SoA
-    double* c[3];
+// Per-slot radiance of the batch ("color_result", main.rs:287).  Most samples of a frame gather no
+// radiance at all (95 % on CornellBox), so the array is sparse: c[slot] holds a value only where
+// bit (slot & 63) of lit[slot >> 6] is set; elsewhere the sample counts as +0 and c is never
+// written or read.  The bounce-0 kernels own whole words (lane i <-> slot i) and store them from a
+// ballot, which also clears what the previous batch left; later contributions set their bit with an
+// atomic OR.  rgb is interleaved so that a contribution touches one cache line.
+struct Sample3 {
+    double* c;                 // [slot][3]
+    unsigned long long* lit;   // [ceil(slots / 64)]
 };
 
 struct Hits {
@@ -213,7 +220,10 @@ void launch_shadow(const Scene& sc, ShadowQueue sq, Live live, Sample3 lsample, 
 bool path_fusable(const Scene& sc, uint32_t bounce);
 bool launch_path(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, Live live, Queue out, Push out_push,
                  ShadowQueue sq, Push sq_push, Sample3 lsample, Counters* ctr, hipStream_t st);
-void launch_accumulate(const Frame& fr, Sample3 lsample, double* accum, hipStream_t st);
+// lsample.c covers every frame of the batch; frames [0, split) have their bits in lsample.lit, the
+// rest (the second lane's) in lit1, both indexed from the lane's first frame
+void launch_accumulate(const Frame& fr, Sample3 lsample, const unsigned long long* lit1, uint32_t split, double* accum,
+                       hipStream_t st);
 // parity entry points
 void launch_build_eye_tables(const Scene& sc, EyeNode* nodes, EyeTri* tris, hipStream_t st);
 void launch_build_tri_shade(const Scene& sc, TriShade* out, hipStream_t st);

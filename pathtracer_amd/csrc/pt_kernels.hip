@@ -620,6 +620,19 @@ __global__ __launch_bounds__(kTravBlock) void k_extend(Scene sc, Frame fr, Queue
     }
 }
 
+// color_result += add for a slot that may not hold a value yet (Sample3).  One lane per slot and
+// launch, so only this lane can set the slot's bit; other bits of the word change under it.
+__device__ __forceinline__ void radiance_add(const Sample3& ls, uint32_t slot, D3 add) {
+    const unsigned long long bit = 1ull << (slot & 63u);
+    double* c = ls.c + (size_t)slot * 3;
+    if (ls.lit[slot >> 6] & bit) {
+        c[0] += add.x; c[1] += add.y; c[2] += add.z;
+    } else {
+        c[0] = 0. + add.x; c[1] = 0. + add.y; c[2] = 0. + add.z;
+        atomicOr(ls.lit + (slot >> 6), bit);
+    }
+}
+
 template <int DEPTH, bool VOTE>
 __global__ __launch_bounds__(kTravBlock) void k_shadow(Scene sc, ShadowQueue sq, Live live, uint32_t wave_rays, Sample3 ls,
                                                    Counters* ctr) {
@@ -648,10 +661,7 @@ __global__ __launch_bounds__(kTravBlock) void k_shadow(Scene sc, ShadowQueue sq,
     auto done = [&](uint32_t i, uint32_t tri, double) {
             if (tri != PT_MISS) return;
             // unoccluded: the light sample counts (one shadow ray per path slot and launch)
-            uint32_t slot = sq.slot[i];
-            ls.c[0][slot] += sq.c[0][i];
-            ls.c[1][slot] += sq.c[1][i];
-            ls.c[2][slot] += sq.c[2][i];
+            radiance_add(ls, sq.slot[i], mk(sq.c[0][i], sq.c[1][i], sq.c[2][i]));
         };
     if (VOTE) {
         trace_range_vote<DEPTH, true, false>(sc, begin, end, pool, stack + threadIdx.x, fetch, done, nn, nt);
@@ -1114,6 +1124,7 @@ struct ShadeOut {
     D3 s_d, s_c;  // shadow ray direction and the radiance it carries if unoccluded
     double s_tmax = 0.;
     RayDiffs n_diff;  // DIFFS: the next ray's differential rays
+    bool lit = false;  // FIRST: the sample's radiance was written (Sample3)
 };
 // the part of a path record the shading needs besides the ray; the fused kernel loads it before
 // it walks the tree, so that the loads' latency is hidden behind the traversal
@@ -1290,11 +1301,21 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
         }
     }
     // color_result += add.  Adding +-0 never changes the sum (it starts at +0), NaN != 0 is true.
-    if (FIRST) {
-        ls.c[0][slot] = 0. + add.x; ls.c[1][slot] = 0. + add.y; ls.c[2][slot] = 0. + add.z;
-    } else if (add.x != 0. || add.y != 0. || add.z != 0.) {
-        ls.c[0][slot] += add.x; ls.c[1][slot] += add.y; ls.c[2][slot] += add.z;
+    if (add.x != 0. || add.y != 0. || add.z != 0.) {
+        if (FIRST) {  // slot == lane index: the caller stores the wave's word of Sample3::lit from r.lit
+            double* c = ls.c + (size_t)slot * 3;
+            c[0] = 0. + add.x; c[1] = 0. + add.y; c[2] = 0. + add.z;
+            r.lit = true;
+        } else {
+            radiance_add(ls, slot, add);
+        }
     }
+}
+// bounce 0: the wave's 64 slots are one word of Sample3::lit (i0 = the wave's first slot, a multiple
+// of 64); called by all lanes of the wave, converged
+__device__ __forceinline__ void store_lit(const Sample3& ls, uint32_t i0, uint32_t end, bool lit) {
+    unsigned long long m = __ballot(lit);
+    if ((threadIdx.x & 63u) == 0 && i0 < end) ls.lit[i0 >> 6] = m;
 }
 
 template <bool NEE, bool DIFFS = false>
@@ -1354,6 +1375,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
         shade_vertex<FIRST, LAST, NEE, PLAIN, false, DIFFS>(sc, fr, bounce, in, i, load_rec<FIRST>(in, i), leaf, t,
                                                             mk(0., 0., 0.), mk(0., 0., 0.), ls, r);
     }
+    if (FIRST) store_lit(ls, i - (threadIdx.x & 63u), n, r.lit);
     if (LAST) return;  // nothing continues
     uint32_t pos = region * out_push.seg_size + compact_slot(r.alive, out_push.counts + region * kCtrStride, lds_a);
     if (r.alive) push_path<NEE, DIFFS>(out, pos, r);
@@ -1423,6 +1445,7 @@ __global__ __launch_bounds__(PathBlock<DEPTH>::value) void k_path(Scene sc, Fram
                                                     : traverse<DEPTH, false, false, kPathBlock>(sc, o, d, 1e-5, t, stack + threadIdx.x, nn, nt);
             shade_vertex<FIRST, LAST, NEE, PLAIN, true>(sc, fr, bounce, in, i, rec, leaf, t, o, d, ls, r);
         }
+        if (FIRST) store_lit(ls, i - (threadIdx.x & 63u), end, r.lit);
         if (!sparse) break;
     }
     if (LAST) return;  // nothing continues
@@ -1438,7 +1461,8 @@ __global__ __launch_bounds__(PathBlock<DEPTH>::value) void k_path(Scene sc, Fram
 }
 
 // accumulate: main.rs:434-436, frames of the batch added in index order (deterministic f64 sum)
-__global__ __launch_bounds__(kBlock) void k_accumulate(Frame fr, Sample3 ls, double* __restrict__ accum) {
+__global__ __launch_bounds__(kBlock) void k_accumulate(Frame fr, Sample3 ls, const unsigned long long* __restrict__ lit1,
+                                                       uint32_t split, double* __restrict__ accum) {
     uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= fr.n_tile_pixels) return;
     uint32_t ty = p / fr.tile_w, tx = p - ty * fr.tile_w;
@@ -1447,7 +1471,13 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(Frame fr, Sample3 ls, dou
     bool drop = (fr.flags & PT_FLAG_DROP_NONFINITE) != 0;
     for (uint32_t s = 0; s < fr.n_samples; ++s) {
         size_t k = (size_t)s * fr.n_tile_pixels + p;
-        double cr = ls.c[0][k], cg = ls.c[1][k], cb = ls.c[2][k];
+        size_t kl = s < split ? k : k - (size_t)split * fr.n_tile_pixels;  // slot within its lane
+        const unsigned long long word = (s < split ? ls.lit : lit1)[kl >> 6];
+        double cr = 0., cg = 0., cb = 0.;  // a sample without a value is +0 (Sample3)
+        if (word >> (kl & 63u) & 1ull) {
+            const double* c = ls.c + k * 3;
+            cr = c[0]; cg = c[1]; cb = c[2];
+        }
         if (drop && !(isfinite(cr) && isfinite(cg) && isfinite(cb))) continue;
         r += cr; g += cg; b += cb;
     }
@@ -1658,9 +1688,10 @@ void launch_shadow(const Scene& sc, ShadowQueue sq, Live live, Sample3 ls, Count
     if (sc.vote_shadow) launch_shadow_v<true>(sc, sq, live, sc.wave_rays, ls, ctr, st);
     else launch_shadow_v<false>(sc, sq, live, 64, ls, ctr, st);
 }
-void launch_accumulate(const Frame& fr, Sample3 ls, double* accum, hipStream_t st) {
+void launch_accumulate(const Frame& fr, Sample3 ls, const unsigned long long* lit1, uint32_t split, double* accum,
+                       hipStream_t st) {
     if (!fr.n_tile_pixels) return;
-    hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(fr.n_tile_pixels)), dim3(kBlock), 0, st, fr, ls, accum);
+    hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(fr.n_tile_pixels)), dim3(kBlock), 0, st, fr, ls, lit1, split, accum);
 }
 void launch_build_eye_tables(const Scene& sc, EyeNode* nodes, EyeTri* tris, hipStream_t st) {
     uint32_t n = std::max(sc.n_nodes, sc.n_tris);
