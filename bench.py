@@ -145,10 +145,13 @@ def main():
         # records (path record 76 B = o, d, T as f64 + slot, +8 B pdf with NEE; hit record 12 B):
         #   extend      primary ray: 12 written; secondary ray: 48 read + 12 written
         #   shade       per ray 12 read; secondary ray: +76 read; per continuing path 76 written;
-        #               per sample 24 written (Lsample)
+        #               per sample 1 bit, per sample that gathered radiance 24 written
         #   path        (extend+shade fused) secondary ray: 76 read; continuing path: 76 written;
-        #               per sample 24 written
-        #   accumulate  per sample 24 read, per pixel and launch 48 (accum read-modify-write)
+        #               per sample 1 bit, per lit sample 24 written
+        #   accumulate  per sample 1 bit, per lit sample 24 read, per pixel and launch 48 (accum
+        #               read-modify-write)
+        # (the radiance of a sample is stored only if it gathered any: DESIGN.md "sparse radiance";
+        # `lit` is counted by the instrumented step)
         # The scene terms 32 V + 36 T are added to the traversing kernel only when the scene does
         # not fit one XCD's L2 (config 5); for a cache-resident scene they are reported as L2-served.
         scene_bytes = data.n_tris * 48 + len(scene.bvh()[0]) * 64
@@ -156,13 +159,14 @@ def main():
         scene_ray = 32.0 * V + 36.0 * T
         rec, hit = 76.0, 12.0
         P = float(samples_per_rank)                 # primary rays of the timed region
+        lit = P * st2["lit_samples"] / max(1, st2["samples"])   # samples that gathered radiance
         S = max(0.0, float(st["rays"]) - P)         # secondary rays == records written
         scene_all = float(st["rays"]) * scene_ray
         per_kind = {
             "extend": P * hit + S * (48.0 + hit),
-            "shade": (P + S) * hit + S * rec + S * rec + P * 24.0,
-            "path": S * rec + S * rec + P * 24.0,
-            "accumulate": P * 24.0 + float(npix) * 48.0 * max(1, kern["accumulate"]["launches"]),
+            "shade": (P + S) * hit + S * rec + S * rec + P / 8.0 + lit * 24.0,
+            "path": S * rec + S * rec + P / 8.0 + lit * 24.0,
+            "accumulate": P / 8.0 + lit * 24.0 + float(npix) * 48.0 * max(1, kern["accumulate"]["launches"]),
             "shadow": float(st["shadow_rays"]) * (56.0 + 24.0 + 4.0),
             "generate": 0.0,
         }
@@ -197,6 +201,7 @@ def main():
             "l2_served_GBs": round(gbs(l2_bytes / launches, avg_ms), 2),
             "nodes_per_ray": round(V, 3), "tris_per_ray": round(T, 3),
             "rays_per_sample": round(st["rays"] / max(1, samples_per_rank), 4),
+            "lit_samples": round(lit / P, 4),
             "kernel_ms": {k: round(v["ms"], 3) for k, v in kern.items()},
             "kernel_launches": {k: v["launches"] for k, v in kern.items()},
             "kernel_share": {k: round(v["ms"] / total_kernel_ms, 4) for k, v in kern.items()} if total_kernel_ms else {},

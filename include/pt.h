@@ -194,6 +194,8 @@ typedef struct pt_stats {
     uint64_t nodes_visited;  /* child boxes slab-tested (32 B each); only with pt_set_profiling(..,2) */
     uint64_t tris_tested;    /* Triangle::intersect calls (triangle_mesh.rs:101) */
     pt_kernel_stat kernel[PT_K_COUNT];
+    uint64_t lit_samples;    /* samples that gathered any radiance (the others are never stored or read:
+                              * DESIGN.md "sparse radiance"); only with pt_set_profiling(..,2) */
 } pt_stats;
 
 typedef struct pt_scene pt_scene;

@@ -657,6 +657,7 @@ int pt_get_stats(pt_scene* s, pt_stats* out) {
     s->stats.shadow_rays = c.shadow_rays;
     s->stats.nodes_visited = c.nodes;
     s->stats.tris_tested = c.tris;
+    s->stats.lit_samples = c.lit;
     *out = s->stats;
     return PT_OK;
 }
@@ -814,7 +815,8 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
         }
         {
             Timer t(s, st, PT_K_ACCUMULATE);
-            ptd::launch_accumulate(fr, w.ls, n_run == 2 ? w.lane[1].lit : nullptr, run[0].fr.n_samples, accum_dev, st);
+            ptd::launch_accumulate(fr, w.ls, n_run == 2 ? w.lane[1].lit : nullptr, run[0].fr.n_samples, accum_dev,
+                                   stats ? ctr : nullptr, st);
         }
         HIP_TRY(hipGetLastError());
     }

@@ -199,7 +199,7 @@ struct Frame {  // per-call constants of generate / shade
 };
 
 struct Counters {  // device-side statistics (pt_stats)
-    unsigned long long rays, shadow_rays, nodes, tris;
+    unsigned long long rays, shadow_rays, nodes, tris, lit;
 };
 
 constexpr int kStackDepth = 32;  // LDS traversal stack entries per lane; builder bounds tree depth
@@ -223,7 +223,7 @@ bool launch_path(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, Li
 // lsample.c covers every frame of the batch; frames [0, split) have their bits in lsample.lit, the
 // rest (the second lane's) in lit1, both indexed from the lane's first frame
 void launch_accumulate(const Frame& fr, Sample3 lsample, const unsigned long long* lit1, uint32_t split, double* accum,
-                       hipStream_t st);
+                       Counters* ctr /* nullptr: no statistics */, hipStream_t st);
 // parity entry points
 void launch_build_eye_tables(const Scene& sc, EyeNode* nodes, EyeTri* tris, hipStream_t st);
 void launch_build_tri_shade(const Scene& sc, TriShade* out, hipStream_t st);

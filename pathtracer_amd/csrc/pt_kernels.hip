@@ -1462,9 +1462,10 @@ __global__ __launch_bounds__(PathBlock<DEPTH>::value) void k_path(Scene sc, Fram
 
 // accumulate: main.rs:434-436, frames of the batch added in index order (deterministic f64 sum)
 __global__ __launch_bounds__(kBlock) void k_accumulate(Frame fr, Sample3 ls, const unsigned long long* __restrict__ lit1,
-                                                       uint32_t split, double* __restrict__ accum) {
+                                                       uint32_t split, double* __restrict__ accum, Counters* ctr) {
     uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= fr.n_tile_pixels) return;
+    uint32_t n_lit = 0;
     uint32_t ty = p / fr.tile_w, tx = p - ty * fr.tile_w;
     size_t pix = (size_t)(fr.y0 + ty) * fr.width + fr.x0 + tx;
     double r = accum[pix * 3], g = accum[pix * 3 + 1], b = accum[pix * 3 + 2];
@@ -1477,11 +1478,13 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(Frame fr, Sample3 ls, con
         if (word >> (kl & 63u) & 1ull) {
             const double* c = ls.c + k * 3;
             cr = c[0]; cg = c[1]; cb = c[2];
+            ++n_lit;
         }
         if (drop && !(isfinite(cr) && isfinite(cg) && isfinite(cb))) continue;
         r += cr; g += cg; b += cb;
     }
     accum[pix * 3] = r; accum[pix * 3 + 1] = g; accum[pix * 3 + 2] = b;
+    if (ctr && n_lit) atomicAdd(&ctr->lit, (unsigned long long)n_lit);
 }
 
 // main.rs:402-405 + 469-481 with samples_per_pixel = 1 (main.rs:386): one jitter pair per frame,
@@ -1689,9 +1692,9 @@ void launch_shadow(const Scene& sc, ShadowQueue sq, Live live, Sample3 ls, Count
     else launch_shadow_v<false>(sc, sq, live, 64, ls, ctr, st);
 }
 void launch_accumulate(const Frame& fr, Sample3 ls, const unsigned long long* lit1, uint32_t split, double* accum,
-                       hipStream_t st) {
+                       Counters* ctr, hipStream_t st) {
     if (!fr.n_tile_pixels) return;
-    hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(fr.n_tile_pixels)), dim3(kBlock), 0, st, fr, ls, lit1, split, accum);
+    hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(fr.n_tile_pixels)), dim3(kBlock), 0, st, fr, ls, lit1, split, accum, ctr);
 }
 void launch_build_eye_tables(const Scene& sc, EyeNode* nodes, EyeTri* tris, hipStream_t st) {
     uint32_t n = std::max(sc.n_nodes, sc.n_tris);

@@ -320,7 +320,7 @@ class Scene:
     def stats(self) -> dict:
         s = L.pt_stats()
         L.check(L.lib.pt_get_stats(self._h, C.byref(s)))
-        out = {k: int(getattr(s, k)) for k in ("samples", "rays", "shadow_rays", "nodes_visited", "tris_tested")}
+        out = {k: int(getattr(s, k)) for k in ("samples", "rays", "shadow_rays", "nodes_visited", "tris_tested", "lit_samples")}
         out["kernel"] = {L.KERNEL_NAMES[i]: {"launches": int(s.kernel[i].launches), "ms": float(s.kernel[i].ms)}
                          for i in range(L.PT_K_COUNT)}
         return out

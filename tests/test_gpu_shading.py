@@ -178,6 +178,7 @@ def test_stats_counters(trio):
     assert st["samples"] == 64 * 64 * 2
     assert st["samples"] <= st["rays"] <= 3 * st["samples"]
     assert st["nodes_visited"] >= 2 * st["rays"] and st["tris_tested"] > st["rays"] // 2
+    assert 0 < st["lit_samples"] < st["samples"] // 2        # most samples gather nothing and are never stored
     k = st["kernel"]
     assert k["extend"]["launches"] == 3 and k["shade"]["launches"] == 3 and k["generate"]["launches"] == 0  # fused into bounce-0 extend/shade
     assert k["extend"]["ms"] > 0 and k["path"]["launches"] == 0   # level 2 counts in the extend kernel: unfused
