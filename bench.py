@@ -29,7 +29,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--spp", type=int, default=32, help="frames per step")
     ap.add_argument("--width", type=int, default=1920)
@@ -139,6 +139,19 @@ def main():
         rays2 = max(1, st2["rays"])
         V = st2["nodes_visited"] / rays2
         T = st2["tris_tested"] / rays2
+        # the same for the primary rays alone (the same frames with bounces = 0)
+        scene.reset_stats()
+        scene.set_profiling(2)
+        cfg0 = pt.Config(width=args.width, height=args.height, bounces=0, seed=1, spp_per_batch=args.spp)
+        scratch = torch.zeros_like(accum)
+        scene.render_device(cfg0, scratch.data_ptr(), ((args.warmup + args.steps) * world + rank) * args.spp, args.spp,
+                            stream=stream)
+        torch.cuda.synchronize(dev)
+        st0 = scene.stats()
+        scene.set_profiling(0)
+        del scratch
+        V0 = st0["nodes_visited"] / max(1, st0["rays"])
+        T0 = st0["tris_tested"] / max(1, st0["rays"])
         # Algorithmic bytes (DESIGN.md "Measurement").  SURVEY.md §8d prices a ray at
         # B_ray = 32 V + 36 T + 128: V child boxes (32 B each), T triangles (36 B) and one path
         # record written by the producer and read by the consumer.  Per kernel, with this build's
@@ -170,11 +183,24 @@ def main():
             "shadow": float(st["shadow_rays"]) * (56.0 + 24.0 + 4.0),
             "generate": 0.0,
         }
-        trav = "path" if kern["path"]["ms"] > kern["extend"]["ms"] else "extend"
+        # which kernel walked the tree for which rays: the fused path kernel every bounce of a shallow
+        # tree, or only the primary bounce of a deep one (the extend kernel then has the secondary rays)
+        if kern["path"]["launches"] and kern["extend"]["launches"]:
+            scene_primary = P * (32.0 * V0 + 36.0 * T0)
+            scene_of = {"path": scene_primary, "extend": scene_all - scene_primary}
+            # deep tree: path = primary bounce only (writes the records of the secondary rays), extend and
+            # shade = the secondary rays (records written by shade: the few survivors of the cull, ignored)
+            per_kind["path"] = S * rec + P / 8.0 + lit * 24.0
+            per_kind["extend"] = S * (48.0 + hit)
+            per_kind["shade"] = S * (hit + rec) + lit * 24.0
+        elif kern["path"]["launches"]:
+            scene_of = {"path": scene_all}
+        else:
+            scene_of = {"extend": scene_all}
         launches = max(1, kern[dom]["launches"])
         avg_ms = kern[dom]["ms"] / launches
-        hbm_bytes = per_kind[dom] + (scene_all if (dom == trav and not resident) else 0.0)
-        l2_bytes = scene_all if (dom == trav and resident) else 0.0
+        hbm_bytes = per_kind[dom] + (0.0 if resident else scene_of.get(dom, 0.0))
+        l2_bytes = scene_of.get(dom, 0.0) if resident else 0.0
         bytes_per_launch = hbm_bytes / launches
         gbs = lambda b, ms: b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         achieved = gbs(bytes_per_launch, avg_ms)
@@ -200,12 +226,13 @@ def main():
             "scene_cache_resident": resident, "scene_bytes": scene_bytes,
             "l2_served_GBs": round(gbs(l2_bytes / launches, avg_ms), 2),
             "nodes_per_ray": round(V, 3), "tris_per_ray": round(T, 3),
+            "nodes_per_primary_ray": round(V0, 3), "tris_per_primary_ray": round(T0, 3),
             "rays_per_sample": round(st["rays"] / max(1, samples_per_rank), 4),
             "lit_samples": round(lit / P, 4),
             "kernel_ms": {k: round(v["ms"], 3) for k, v in kern.items()},
             "kernel_launches": {k: v["launches"] for k, v in kern.items()},
             "kernel_share": {k: round(v["ms"] / total_kernel_ms, 4) for k, v in kern.items()} if total_kernel_ms else {},
-            "kernel_GBs": {k: round(gbs(per_kind[k] + (scene_all if (k == trav and not resident) else 0.0), v["ms"]), 1)
+            "kernel_GBs": {k: round(gbs(per_kind[k] + (0.0 if resident else scene_of.get(k, 0.0)), v["ms"]), 1)
                            for k, v in kern.items() if v["launches"]},
             "whole_path_GBs": round(gbs(whole, total_kernel_ms), 2),
         }
