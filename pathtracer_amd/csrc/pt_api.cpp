@@ -533,7 +533,9 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
         const ptd::Material& m = mats[d->prims[k].material];
         if (m.kind == PT_MAT_LAMBERT && (m.emission[0] != 0. || m.emission[1] != 0. || m.emission[2] != 0.)) emissive_prim = true;
     }
-    if ((rc = upload(s->d_emissive, emissive.data(), emissive.size())) != PT_OK) return rc;
+    DevBuf d_emissive_leaf;
+    if ((rc = upload(d_emissive_leaf, emissive.data(), emissive.size())) != PT_OK) return rc;
+    HIP_TRY(s->d_emissive.alloc(std::max<size_t>(emissive.size(), 1) * sizeof(ptd::EmitTri)));
     if ((rc = upload(s->d_lights, lights.data(), lights.size())) != PT_OK) return rc;
     if ((rc = upload(s->d_prims, prims.data(), prims.size())) != PT_OK) return rc;
 
@@ -548,7 +550,7 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
     dv.mats = s->d_mats.as<ptd::Material>();
     dv.texs = s->d_texs.as<ptd::Texture>();
     dv.lights = s->d_lights.as<ptd::Light>();
-    dv.emissive = s->d_emissive.as<uint32_t>();
+    dv.emissive = s->d_emissive.as<ptd::EmitTri>();
     dv.n_emissive = (uint32_t)emissive.size();
     // last-bounce cull (pt_kernels.hip may_reach_emitter): needs a black background and emitters that
     // are a few triangles; PT_LIGHT_CULL=0 switches it off (tests render both ways)
@@ -589,6 +591,8 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
     HIP_TRY(s->d_tri_shade.alloc(std::max<size_t>(d->n_tris, 1) * sizeof(ptd::TriShade)));
     dv.tri_shade = s->d_tri_shade.as<ptd::TriShade>();
     ptd::launch_build_tri_shade(dv, s->d_tri_shade.as<ptd::TriShade>(), nullptr);
+    ptd::launch_build_emitters(dv, d_emissive_leaf.as<uint32_t>(), dv.n_emissive, s->d_emissive.as<ptd::EmitTri>(), nullptr);
+    HIP_TRY(hipDeviceSynchronize());  // d_emissive_leaf goes out of scope with this function
     dv.eye_nodes = nullptr;
     dv.eye_tris = nullptr;
     const char* eye_env = getenv("PT_EYE_TABLES");
@@ -766,6 +770,7 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
         fr.flags = diffs ? P->flags : (P->flags & ~(uint32_t)PT_FLAG_PROPAGATE_DIFFS);
         fr.diff_size = P->diff_size;
         fr.jitter = w.jitter.as<double>() + (size_t)b0 * 2;
+        ptd::finish_frame(fr);
         // the generate stage is fused into the bounce-0 extend and shade kernels (they rebuild the
         // camera ray from the pixel): no primary-ray queue is written or read.
         const int n_run = (two && ns >= 2) ? 2 : 1;
@@ -902,6 +907,7 @@ int pt_generate_rays(pt_scene* s, const pt_render_params* P, uint64_t sample, pt
     fr.width = P->width; fr.height = P->height; fr.x0 = P->x0; fr.y0 = P->y0; fr.tile_w = tw; fr.tile_h = th;
     fr.n_tile_pixels = npix; fr.n_samples = 1; fr.sample_base = sample; fr.seed = P->seed;
     fr.max_bounces = P->max_bounces; fr.flags = P->flags; fr.jitter = jit.as<double>();
+    ptd::finish_frame(fr);
     ptd::launch_generate_rays(s->dev, fr, out.as<double>(), nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
@@ -938,6 +944,7 @@ int pt_sample_brdf(pt_scene* s, const pt_ray* rays, const uint32_t* tri_id, cons
     std::memset(&fr, 0, sizeof fr);
     fr.width = width; fr.height = height; fr.tile_w = width; fr.tile_h = height; fr.n_tile_pixels = width * height;
     fr.n_samples = 1; fr.sample_base = sample; fr.seed = seed; fr.flags = flags; fr.jitter = jit.as<double>();
+    ptd::finish_frame(fr);
     double* o = d_out.as<double>();
     ptd::launch_sample_brdf(s->dev, fr, bounce, d_rays.as<double>(), d_tri.as<uint32_t>(), d_t.as<double>(),
                             d_pix.as<uint32_t>(), (uint32_t)n, o, o + 3 * n, o + 6 * n, o + 7 * n, o + 10 * n, nullptr);

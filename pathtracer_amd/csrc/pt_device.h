@@ -73,7 +73,24 @@ struct EyeTri {
     uint32_t pad;
 };
 constexpr uint32_t kEyeTableMaxTris = 1u << 16;
-constexpr uint32_t kMaxCullEmitters = 8;  // more emitters than this and testing them all costs more than it saves
+constexpr uint32_t kMaxCullEmitters = 8;
+// An emissive triangle as the last-bounce cull tests it: the origin-independent part of the
+// triangle test (v0, e0, e1, e0 x e1 in f64), computed once on the device by the test's own code.
+struct EmitTri {
+    double v0[3], e0[3], e1[3], normal[3];
+};
+
+// n / d for n < 2^31 as (n * mul) >> shift (exact: mul = ceil(2^shift / d), shift = 31 + ceil(log2 d)).
+// The slot -> (frame, pixel) -> (x, y) mapping runs once per path vertex; a hardware-less u32
+// division costs ~25 instructions, this one 2.
+struct FastDiv {
+    uint32_t mul, shift;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    return {(uint32_t)(((1ull << (31 + l)) + d - 1) / d), 31 + l};
+}  // more emitters than this and testing them all costs more than it saves
 
 struct Light {  // one emissive triangle, or (sphere != 0) an emissive sphere: v0 = centre, v1[0] = radius (NEE)
     double v0[3], v1[3], v2[3];
@@ -98,7 +115,7 @@ struct Scene {
     // Emissive triangles (leaf-order indices), for the last-bounce cull: a ray spawned at the
     // second-to-last vertex can only add radiance if it hits one of them (black background), so one
     // that passes none of their triangle tests is dropped instead of being queued and traced.
-    const uint32_t* emissive;
+    const EmitTri* emissive;
     uint32_t n_emissive;
     uint32_t cull_last;  // the cull applies to this scene (black background, few emitters, no emissive sphere)
     const Prim* prims;  // tested against every ray before the tree is walked; hit id PT_PRIM_BASE + k
@@ -196,7 +213,15 @@ struct Frame {  // per-call constants of generate / shade
     uint32_t flags;
     const double* jitter;  // [n_samples][2] frame jitters, already scaled by the pixel size
     double diff_size;      // CONFIG.diff_size (PT_FLAG_PROPAGATE_DIFFS)
+    // derived by finish_frame(): what every lane would otherwise recompute
+    FastDiv div_pixels, div_tile_w;  // / n_tile_pixels, / tile_w
+    double aspect;                   // (double)width / (double)height (main.rs:412-424 extended, F7)
 };
+inline void finish_frame(Frame& fr) {
+    fr.div_pixels = make_fastdiv(fr.n_tile_pixels ? fr.n_tile_pixels : 1u);
+    fr.div_tile_w = make_fastdiv(fr.tile_w ? fr.tile_w : 1u);
+    fr.aspect = (double)fr.width / (double)fr.height;
+}
 
 struct Counters {  // device-side statistics (pt_stats)
     unsigned long long rays, shadow_rays, nodes, tris, lit;
@@ -227,6 +252,7 @@ void launch_accumulate(const Frame& fr, Sample3 lsample, const unsigned long lon
 // parity entry points
 void launch_build_eye_tables(const Scene& sc, EyeNode* nodes, EyeTri* tris, hipStream_t st);
 void launch_build_tri_shade(const Scene& sc, TriShade* out, hipStream_t st);
+void launch_build_emitters(const Scene& sc, const uint32_t* leaf, uint32_t n, EmitTri* out, hipStream_t st);
 void launch_leaf_to_global(const Scene& sc, uint32_t* tri, uint32_t n, hipStream_t st);
 void launch_sample_brdf(const Scene& sc, const Frame& fr, uint32_t bounce, const double* rays /* pt_ray[n] */,
                         const uint32_t* tri_leaf, const double* t, const uint32_t* pixel, uint32_t n, double* f,

@@ -82,8 +82,9 @@ __host__ __device__ __forceinline__ void uniform2(uint64_t seed, uint32_t pixel,
 struct PixelArgs {
     double x, y, ddx, ddy;
 };
-__device__ __forceinline__ PixelArgs pixel_args(uint32_t px, uint32_t py, uint32_t w, uint32_t h, double dx, double dy) {
-    double aspect = (double)w / (double)h;  // 1.0 for the reference's square images (F7)
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) { return (uint32_t)(((unsigned long long)n * f.mul) >> f.shift); }
+__device__ __forceinline__ PixelArgs pixel_args(uint32_t px, uint32_t py, uint32_t w, uint32_t h, double dx, double dy,
+                                                double aspect /* (double)w / (double)h: 1.0 for the reference's square images (F7) */) {
     double pixel_size_x = 1. / (double)w, pixel_size_y = 1. / (double)h;
     double pixel_ndc_x = ((double)px + 0.5) / (double)w;
     double pixel_ndc_y = ((double)py + 0.5) / (double)h;
@@ -576,9 +577,9 @@ __global__ __launch_bounds__(kTravBlock) void k_extend(Scene sc, Frame fr, Queue
     uint32_t nn = 0, nt = 0;
     auto fetch = [&](uint32_t i, D3& o, D3& d, double& t_min, double& t_max) {
             if (PRIMARY) {
-                uint32_t s = i / fr.n_tile_pixels, p = i - s * fr.n_tile_pixels;
-                uint32_t ty = p / fr.tile_w, tx = p - ty * fr.tile_w;
-                PixelArgs a = pixel_args(fr.x0 + tx, fr.y0 + ty, fr.width, fr.height, fr.jitter[2 * s], fr.jitter[2 * s + 1]);
+                uint32_t s = fdiv(i, fr.div_pixels), p = i - s * fr.n_tile_pixels;
+                uint32_t ty = fdiv(p, fr.div_tile_w), tx = p - ty * fr.tile_w;
+                PixelArgs a = pixel_args(fr.x0 + tx, fr.y0 + ty, fr.width, fr.height, fr.jitter[2 * s], fr.jitter[2 * s + 1], fr.aspect);
                 o = ld3(sc.cam.eye);
                 d = camera_dir(sc.cam, a.x, a.y);
             } else {
@@ -681,8 +682,8 @@ __global__ __launch_bounds__(kTravBlock) void k_shadow(Scene sc, ShadowQueue sq,
 __global__ __launch_bounds__(kBlock) void k_generate_rays(Scene sc, Frame fr, double* __restrict__ rays) {
     uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= fr.n_tile_pixels) return;
-    uint32_t ty = p / fr.tile_w, tx = p - ty * fr.tile_w;
-    PixelArgs a = pixel_args(fr.x0 + tx, fr.y0 + ty, fr.width, fr.height, fr.jitter[0], fr.jitter[1]);
+    uint32_t ty = fdiv(p, fr.div_tile_w), tx = p - ty * fr.tile_w;
+    PixelArgs a = pixel_args(fr.x0 + tx, fr.y0 + ty, fr.width, fr.height, fr.jitter[0], fr.jitter[1], fr.aspect);
     D3 dir = camera_dir(sc.cam, a.x, a.y);
     double* r = rays + (size_t)p * 8;
     r[0] = sc.cam.eye[0]; r[1] = sc.cam.eye[1]; r[2] = sc.cam.eye[2];
@@ -1041,7 +1042,7 @@ __device__ __forceinline__ void hit_geometry(const Scene& sc, uint32_t leaf, D3 
 // scene.rs:47-54: the differential rays of the camera ray of `pixel` in frame `s` of the batch
 __device__ __forceinline__ RayDiffs camera_diffs(const Scene& sc, const Frame& fr, D3 eye, uint32_t pixel, uint32_t s) {
     PixelArgs a = pixel_args(pixel % fr.width, pixel / fr.width, fr.width, fr.height, fr.jitter[2 * s],
-                             fr.jitter[2 * s + 1]);
+                             fr.jitter[2 * s + 1], fr.aspect);
     return {eye, eye, camera_dir(sc.cam, a.x + a.ddx, a.y), camera_dir(sc.cam, a.x, a.y + a.ddy)};
 }
 __device__ __forceinline__ D3 diffuse_of(const Scene& sc, const Material& m, uint32_t leaf, D3 o,
@@ -1100,10 +1101,26 @@ __device__ __forceinline__ bool finite3(D3 a) { return (a.x - a.x == 0.) && (a.y
 __device__ __forceinline__ bool may_reach_emitter(const Scene& sc, D3 o, D3 d, D3 T) {
     if (!(finite3(o) && finite3(d) && finite3(T))) return true;
     for (uint32_t k = 0; k < sc.n_emissive; ++k) {
+        const EmitTri& e = sc.emissive[k];  // uniform index: scalar loads
+        TriPre p;  // tri_pre() with its origin-independent part read from the table
+        p.e0 = ld3(e.e0); p.e1 = ld3(e.e1); p.normal = ld3(e.normal);
+        p.vo = ld3(e.v0) - o;
+        p.num = dot(p.vo, p.normal);
         double t, v, w;
-        if (tri_test(load_tri(sc, sc.emissive[k]), o, d, 1e-5, 1.7976931348623157e308, t, v, w)) return true;
+        if (tri_test_core(p, d, 1e-5, 1.7976931348623157e308, t, v, w)) return true;
     }
     return false;
+}
+__global__ void k_build_emitters(Scene sc, const uint32_t* leaf, uint32_t n, EmitTri* out) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const TriV tr = load_tri(sc, leaf[k]);
+    const TriPre p = tri_pre(tr, mk(0., 0., 0.));
+    EmitTri& e = out[k];
+    e.v0[0] = tr.v0.x; e.v0[1] = tr.v0.y; e.v0[2] = tr.v0.z;
+    e.e0[0] = p.e0.x; e.e0[1] = p.e0.y; e.e0[2] = p.e0.z;
+    e.e1[0] = p.e1.x; e.e1[1] = p.e1.y; e.e1[2] = p.e1.z;
+    e.normal[0] = p.normal.x; e.normal[1] = p.normal.y; e.normal[2] = p.normal.z;
 }
 
 // The shading of one path vertex (main.rs:292-315), shared by the shade kernel and the fused path
@@ -1146,14 +1163,14 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
                                              const Sample3& ls, ShadeOut& r) {
     const uint32_t slot = rec.slot;
     r.slot = slot;
-    uint32_t s = slot / fr.n_tile_pixels, p = slot - s * fr.n_tile_pixels;
-    uint32_t ty = p / fr.tile_w, tx = p - ty * fr.tile_w;
+    uint32_t s = fdiv(slot, fr.div_pixels), p = slot - s * fr.n_tile_pixels;
+    uint32_t ty = fdiv(p, fr.div_tile_w), tx = p - ty * fr.tile_w;
     uint32_t pixel = (fr.y0 + ty) * fr.width + fr.x0 + tx;
     uint64_t sample = fr.sample_base + s;
     constexpr bool kNeedRay = !LAST || NEE;
     if (!FUSED) {  // FUSED: the caller traced the ray in this kernel and still holds it
         if (FIRST) {
-            PixelArgs a = pixel_args(fr.x0 + tx, fr.y0 + ty, fr.width, fr.height, fr.jitter[2 * s], fr.jitter[2 * s + 1]);
+            PixelArgs a = pixel_args(fr.x0 + tx, fr.y0 + ty, fr.width, fr.height, fr.jitter[2 * s], fr.jitter[2 * s + 1], fr.aspect);
             o = ld3(sc.cam.eye);
             d = camera_dir(sc.cam, a.x, a.y);
         } else if (kNeedRay) {
@@ -1429,9 +1446,9 @@ __global__ __launch_bounds__(PathBlock<DEPTH>::value) void k_path(Scene sc, Fram
         if (i < end) {
             D3 o, d;
             if (FIRST) {
-                uint32_t s = i / fr.n_tile_pixels, p = i - s * fr.n_tile_pixels;
-                uint32_t ty = p / fr.tile_w, tx = p - ty * fr.tile_w;
-                PixelArgs a = pixel_args(fr.x0 + tx, fr.y0 + ty, fr.width, fr.height, fr.jitter[2 * s], fr.jitter[2 * s + 1]);
+                uint32_t s = fdiv(i, fr.div_pixels), p = i - s * fr.n_tile_pixels;
+                uint32_t ty = fdiv(p, fr.div_tile_w), tx = p - ty * fr.tile_w;
+                PixelArgs a = pixel_args(fr.x0 + tx, fr.y0 + ty, fr.width, fr.height, fr.jitter[2 * s], fr.jitter[2 * s + 1], fr.aspect);
                 o = ld3(sc.cam.eye);
                 d = camera_dir(sc.cam, a.x, a.y);
             } else {
@@ -1466,7 +1483,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(Frame fr, Sample3 ls, con
     uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= fr.n_tile_pixels) return;
     uint32_t n_lit = 0;
-    uint32_t ty = p / fr.tile_w, tx = p - ty * fr.tile_w;
+    uint32_t ty = fdiv(p, fr.div_tile_w), tx = p - ty * fr.tile_w;
     size_t pix = (size_t)(fr.y0 + ty) * fr.width + fr.x0 + tx;
     double r = accum[pix * 3], g = accum[pix * 3 + 1], b = accum[pix * 3 + 2];
     bool drop = (fr.flags & PT_FLAG_DROP_NONFINITE) != 0;
@@ -1700,6 +1717,10 @@ void launch_build_eye_tables(const Scene& sc, EyeNode* nodes, EyeTri* tris, hipS
     uint32_t n = std::max(sc.n_nodes, sc.n_tris);
     if (!n) return;
     hipLaunchKernelGGL(k_build_eye_tables, dim3(blocks_for(n)), dim3(kBlock), 0, st, sc, nodes, tris);
+}
+void launch_build_emitters(const Scene& sc, const uint32_t* leaf, uint32_t n, EmitTri* out, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_build_emitters, dim3(blocks_for(n)), dim3(kBlock), 0, st, sc, leaf, n, out);
 }
 void launch_build_tri_shade(const Scene& sc, TriShade* out, hipStream_t st) {
     if (!sc.n_tris) return;
