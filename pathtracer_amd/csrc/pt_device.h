@@ -216,11 +216,23 @@ struct Frame {  // per-call constants of generate / shade
     // derived by finish_frame(): what every lane would otherwise recompute
     FastDiv div_pixels, div_tile_w;  // / n_tile_pixels, / tile_w
     double aspect;                   // (double)width / (double)height (main.rs:412-424 extended, F7)
+    // Slot order inside a frame: 8x8-pixel blocks (a wave's 64 primary rays cover a square, not a
+    // 64x1 strip: they walk the same part of the tree), then the strip right of the last whole block
+    // column, then the rows below the last whole block row, both row by row.
+    uint32_t w8, h8, n8, bw, rw;     // tile_w & ~7, tile_h & ~7, w8 * h8, w8 / 8, tile_w - w8 (0 -> 1 for the divisor)
+    FastDiv div_bw, div_rw;
 };
 inline void finish_frame(Frame& fr) {
     fr.div_pixels = make_fastdiv(fr.n_tile_pixels ? fr.n_tile_pixels : 1u);
     fr.div_tile_w = make_fastdiv(fr.tile_w ? fr.tile_w : 1u);
     fr.aspect = (double)fr.width / (double)fr.height;
+    fr.w8 = fr.tile_w & ~7u;
+    fr.h8 = fr.tile_h & ~7u;
+    fr.n8 = fr.w8 * fr.h8;
+    fr.bw = fr.w8 >> 3;
+    fr.rw = fr.tile_w - fr.w8;
+    fr.div_bw = make_fastdiv(fr.bw ? fr.bw : 1u);
+    fr.div_rw = make_fastdiv(fr.rw ? fr.rw : 1u);
 }
 
 struct Counters {  // device-side statistics (pt_stats)

@@ -83,6 +83,32 @@ struct PixelArgs {
     double x, y, ddx, ddy;
 };
 __device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) { return (uint32_t)(((unsigned long long)n * f.mul) >> f.shift); }
+// slot within a frame <-> pixel of the tile (Frame: 8x8 blocks, right strip, bottom rows)
+__device__ __forceinline__ void slot_pixel(const Frame& fr, uint32_t p, uint32_t& tx, uint32_t& ty) {
+    if (p < fr.n8) {
+        uint32_t b = p >> 6, w = p & 63u;
+        uint32_t by = fdiv(b, fr.div_bw), bx = b - by * fr.bw;
+        tx = bx * 8 + (w & 7u);
+        ty = by * 8 + (w >> 3);
+        return;
+    }
+    uint32_t q = p - fr.n8;
+    const uint32_t right = fr.rw * fr.h8;
+    if (q < right) {
+        ty = fdiv(q, fr.div_rw);
+        tx = fr.w8 + (q - ty * fr.rw);
+    } else {
+        q -= right;
+        uint32_t yy = fdiv(q, fr.div_tile_w);
+        tx = q - yy * fr.tile_w;
+        ty = fr.h8 + yy;
+    }
+}
+__device__ __forceinline__ uint32_t pixel_slot(const Frame& fr, uint32_t tx, uint32_t ty) {
+    if (tx < fr.w8 && ty < fr.h8) return (((ty >> 3) * fr.bw + (tx >> 3)) << 6) + ((ty & 7u) << 3) + (tx & 7u);
+    if (ty < fr.h8) return fr.n8 + ty * fr.rw + (tx - fr.w8);
+    return fr.n8 + fr.rw * fr.h8 + (ty - fr.h8) * fr.tile_w + tx;
+}
 __device__ __forceinline__ PixelArgs pixel_args(uint32_t px, uint32_t py, uint32_t w, uint32_t h, double dx, double dy,
                                                 double aspect /* (double)w / (double)h: 1.0 for the reference's square images (F7) */) {
     double pixel_size_x = 1. / (double)w, pixel_size_y = 1. / (double)h;
@@ -578,7 +604,8 @@ __global__ __launch_bounds__(kTravBlock) void k_extend(Scene sc, Frame fr, Queue
     auto fetch = [&](uint32_t i, D3& o, D3& d, double& t_min, double& t_max) {
             if (PRIMARY) {
                 uint32_t s = fdiv(i, fr.div_pixels), p = i - s * fr.n_tile_pixels;
-                uint32_t ty = fdiv(p, fr.div_tile_w), tx = p - ty * fr.tile_w;
+                uint32_t ty, tx;
+                slot_pixel(fr, p, tx, ty);
                 PixelArgs a = pixel_args(fr.x0 + tx, fr.y0 + ty, fr.width, fr.height, fr.jitter[2 * s], fr.jitter[2 * s + 1], fr.aspect);
                 o = ld3(sc.cam.eye);
                 d = camera_dir(sc.cam, a.x, a.y);
@@ -1164,7 +1191,8 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
     const uint32_t slot = rec.slot;
     r.slot = slot;
     uint32_t s = fdiv(slot, fr.div_pixels), p = slot - s * fr.n_tile_pixels;
-    uint32_t ty = fdiv(p, fr.div_tile_w), tx = p - ty * fr.tile_w;
+    uint32_t ty, tx;
+    slot_pixel(fr, p, tx, ty);
     uint32_t pixel = (fr.y0 + ty) * fr.width + fr.x0 + tx;
     uint64_t sample = fr.sample_base + s;
     constexpr bool kNeedRay = !LAST || NEE;
@@ -1447,7 +1475,8 @@ __global__ __launch_bounds__(PathBlock<DEPTH>::value) void k_path(Scene sc, Fram
             D3 o, d;
             if (FIRST) {
                 uint32_t s = fdiv(i, fr.div_pixels), p = i - s * fr.n_tile_pixels;
-                uint32_t ty = fdiv(p, fr.div_tile_w), tx = p - ty * fr.tile_w;
+                uint32_t ty, tx;
+                slot_pixel(fr, p, tx, ty);
                 PixelArgs a = pixel_args(fr.x0 + tx, fr.y0 + ty, fr.width, fr.height, fr.jitter[2 * s], fr.jitter[2 * s + 1], fr.aspect);
                 o = ld3(sc.cam.eye);
                 d = camera_dir(sc.cam, a.x, a.y);
@@ -1487,8 +1516,9 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(Frame fr, Sample3 ls, con
     size_t pix = (size_t)(fr.y0 + ty) * fr.width + fr.x0 + tx;
     double r = accum[pix * 3], g = accum[pix * 3 + 1], b = accum[pix * 3 + 2];
     bool drop = (fr.flags & PT_FLAG_DROP_NONFINITE) != 0;
+    const uint32_t slot_in_frame = pixel_slot(fr, tx, ty);
     for (uint32_t s = 0; s < fr.n_samples; ++s) {
-        size_t k = (size_t)s * fr.n_tile_pixels + p;
+        size_t k = (size_t)s * fr.n_tile_pixels + slot_in_frame;
         size_t kl = s < split ? k : k - (size_t)split * fr.n_tile_pixels;  // slot within its lane
         const unsigned long long word = (s < split ? ls.lit : lit1)[kl >> 6];
         double cr = 0., cg = 0., cb = 0.;  // a sample without a value is +0 (Sample3)
