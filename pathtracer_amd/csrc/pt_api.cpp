@@ -684,10 +684,10 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
                        P->max_bounces > 0;
     // Frames in flight per pass.  Every launch ends in a tail that does not shrink with the batch (the
     // longest rays of the 10M-triangle scene take ~0.4 ms on their own; measured 0.30 + 0.47 ms per
-    // frame for its primary kernel at 4K), so batches are large: ~64M paths by default (~13 GB of
+    // frame for its primary kernel at 4K), so batches are large: ~128M paths by default (~26 GB of
     // queues out of 288), halved while the allocation does not fit.
     uint32_t spp = P->spp_per_batch;
-    if (spp == 0) spp = std::max<uint32_t>(1u, (1u << 26) / npix);
+    if (spp == 0) spp = std::max<uint32_t>(1u, (1u << 27) / npix);
     spp = std::min(spp, P->sample_count);
     spp = std::min<uint32_t>(spp, std::max<uint32_t>(1u, (1u << 30) / npix));
     bool two = false;
