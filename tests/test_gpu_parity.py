@@ -371,7 +371,7 @@ def test_config5_full_size_heightfield_10m(gpu, monkeypatch):
     assert acc.tobytes() == whole.tobytes()
     data.bvh_nodes, data.bvh_tri_order = nodes, order      # same tree, no second 10 M build
     for env in (dict(PT_TRAV_VOTE="0", PT_TRAV_VOTE_SHADOW="0", PT_FUSE="0", PT_PIPELINE="0"),
-                dict(PT_PERSISTENT="0", PT_WAVE_RAYS="1024")):
+                dict(PT_PERSISTENT="0", PT_WAVE_RAYS="1024", PT_LIGHT_CULL="0")):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         other = pt.Scene(data, gpu)
@@ -379,6 +379,36 @@ def test_config5_full_size_heightfield_10m(gpu, monkeypatch):
             monkeypatch.delenv(k)
         assert other.render(cfg).tobytes() == whole.tobytes(), env
         del other
+
+
+@pytest.mark.parametrize("name,kw,width,height,spp,tol,frac", [
+    ("glossy_planes", dict(glossy=True), 1920, 1080, 4, 1e-6, 5e-3),      # BASELINE configs[2]
+    ("Test", dict(textures=True), 3840, 2160, 2, 1e-9, 2e-3),             # BASELINE configs[3]
+])
+def test_baseline_full_size_glossy_and_textured(gpu, name, kw, width, height, spp, tol, frac):
+    # configs[2] and configs[3] at their full image sizes: a strided set of full rows against the
+    # oracle (same frames, same RNG streams) and the size-independent properties of the render
+    data = pt.scene_data(name, **kw)
+    scene, oracle = pt.Scene(data, gpu), O.OracleScene(data)
+    cfg = pt.Config(width=width, height=height, samples_pr_pixel=spp, bounces=2, seed=2, drop_nonfinite=True)
+    whole = scene.render(cfg)
+    assert np.isfinite(whole).all() and whole.mean() > 1e-3
+    rows = range(7, height, height // 24)
+    ref = np.zeros_like(whole)
+    for y in rows:
+        oracle.render(cfg, ref, tile=(0, y, width, y + 1), threads=16)
+    sub, rsub = whole[list(rows)], ref[list(rows)]
+    assert (np.abs(sub - rsub) > tol * np.maximum(1.0, np.abs(rsub))).mean() < frac
+    assert abs(sub.mean() - rsub.mean()) <= 1e-3 * rsub.mean()
+    acc = scene.render(cfg, None, sample_begin=0, sample_count=1)
+    scene.render(cfg, acc, sample_begin=1, sample_count=spp - 1)
+    assert acc.tobytes() == whole.tobytes()
+    acc = np.zeros_like(whole)
+    for x0, x1 in ((0, width // 3), (width // 3, width)):
+        scene.render(cfg, acc, tile=(x0, 0, x1, height))
+    assert acc.tobytes() == whole.tobytes()
+    nee = scene.render(pt.Config(width=width, height=height, samples_pr_pixel=1, bounces=2, seed=2, nee=True, drop_nonfinite=True))
+    assert np.isfinite(nee).all() and nee.mean() > 1e-3
 
 
 @pytest.mark.parametrize("name", ["CornellBox", "Test", "glossy_planes", "heightfield40"])
