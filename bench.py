@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--scene", default="CornellBox", help="models/<scene>.obj, or 'heightfield' (SURVEY config 5)")
     ap.add_argument("--cells", type=int, default=2236, help="heightfield resolution (2236 -> 9,999,392 triangles)")
     ap.add_argument("--bounces", type=int, default=2)
+    ap.add_argument("--nee", action="store_true", help="next-event estimation (shadow rays) on")
+    ap.add_argument("--textures", action="store_true", help="load map_Kd textures (BASELINE configs[3]: --scene Test)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     args = ap.parse_args()
 
@@ -69,9 +71,10 @@ def main():
         from pathtracer_amd.synthetic import heightfield_box
         data = heightfield_box(args.cells)
     else:
-        data = pt.scene_data(args.scene)
+        data = pt.scene_data(args.scene, textures=args.textures)
     scene = pt.Scene(data, device=local_rank)
-    cfg = pt.Config(width=args.width, height=args.height, bounces=args.bounces, seed=1, spp_per_batch=args.spp)
+    cfg = pt.Config(width=args.width, height=args.height, bounces=args.bounces, seed=1, spp_per_batch=args.spp,
+                    nee=args.nee)
     accum = torch.zeros((args.height, args.width, 3), dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     npix = args.width * args.height
@@ -142,7 +145,7 @@ def main():
         # the same for the primary rays alone (the same frames with bounces = 0)
         scene.reset_stats()
         scene.set_profiling(2)
-        cfg0 = pt.Config(width=args.width, height=args.height, bounces=0, seed=1, spp_per_batch=args.spp)
+        cfg0 = pt.Config(width=args.width, height=args.height, bounces=0, seed=1, spp_per_batch=args.spp, nee=args.nee)
         scratch = torch.zeros_like(accum)
         scene.render_device(cfg0, scratch.data_ptr(), ((args.warmup + args.steps) * world + rank) * args.spp, args.spp,
                             stream=stream)
@@ -245,7 +248,7 @@ def main():
             oracle = O.OracleScene(data)
             threads = max(1, min(O.lib.orc_hardware_threads(), 16, len(os.sched_getaffinity(0))))
             acc = np.zeros((args.height, args.width, 3))
-            cpu_cfg = pt.Config(width=args.width, height=args.height, bounces=args.bounces, seed=1)
+            cpu_cfg = pt.Config(width=args.width, height=args.height, bounces=args.bounces, seed=1, nee=args.nee)
             n_frames, c0 = 0, time.perf_counter()
             while True:
                 oracle.render(cpu_cfg, acc, sample_begin=n_frames, sample_count=1, threads=threads, use_bvh=True)
@@ -263,7 +266,7 @@ def main():
             "data": (f"synthetic heightfield box, {data.n_tris} triangles, seed 12345" if args.scene == "heightfield"
                      else f"reference scene models/{args.scene}.obj") + ", counter-based RNG (no dataset)",
             "config": {"workload": f"{args.scene}{'' if args.scene == 'heightfield' else '.obj'} {args.width}x{args.height} "
-                                   f"bounces={args.bounces}, {args.spp} spp per step per GPU"
+                                   f"bounces={args.bounces}{', NEE' if args.nee else ''}{', textures' if args.textures else ''}, {args.spp} spp per step per GPU"
                                    + (" (BASELINE.json configs[1])" if args.scene == "CornellBox" else ""),
                        "triangles": data.n_tris,
                        "partitioning": "sample ranges + one RCCL reduce" if world > 1 else "single GPU",

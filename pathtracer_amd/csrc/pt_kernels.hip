@@ -1308,6 +1308,7 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
                     r.s_c = T * f * ld3(L.emission) * (cosn * wgt / p_l);
                     r.s_d = wl;
                     r.s_tmax = dist * (1. - 1e-9);
+                    r.n_o = position;  // the shadow ray starts here whether or not the path goes on (roulette)
                     r.shadow = true;
                 }
             }

@@ -145,8 +145,17 @@ def test_gpu_russian_roulette_matches_oracle(gpu):
     assert np.allclose(img, ref, rtol=1e-12, atol=0)
     cpl = pt.scene_data("CornellBox")
     s2, o2 = pt.Scene(cpl, gpu), O.OracleScene(cpl)
-    cfg = pt.Config(dim=64, samples_pr_pixel=4, bounces=7, russian_roulette=True, seed=2)
-    a, b = s2.render(cfg), o2.render(cfg)
+    for nee in (False, True):   # with NEE an absorbed path still casts the light sample of its last vertex
+        cfg = pt.Config(dim=64, samples_pr_pixel=4, bounces=7, russian_roulette=True, seed=2, nee=nee)
+        a, b = s2.render(cfg), o2.render(cfg)
+        assert (np.abs(a - b) > 1e-9 * np.maximum(1.0, np.abs(b))).mean() < 2e-3, nee
+    # a scene with occluders (the heightfield's bumps shadow each other): the light sample of an
+    # absorbed path must start at its last vertex
+    from pathtracer_amd.synthetic import heightfield_box
+    hf = heightfield_box(cells=24)
+    s3, o3 = pt.Scene(hf, gpu), O.OracleScene(hf)
+    cfg = pt.Config(dim=48, samples_pr_pixel=4, bounces=8, russian_roulette=True, seed=3, nee=True)
+    a, b = s3.render(cfg), o3.render(cfg)
     assert (np.abs(a - b) > 1e-9 * np.maximum(1.0, np.abs(b))).mean() < 2e-3
 
 
