@@ -207,6 +207,7 @@ void resolve_scheduling(ptd::Scene& dv) {
     dv.vote_secondary = flag("PT_TRAV_VOTE", deep);
     dv.vote_shadow = flag("PT_TRAV_VOTE_SHADOW", deep);
     dv.fuse = flag("PT_FUSE", true);
+    dv.fuse_shadow = flag("PT_FUSE_SHADOW", true) && dv.fuse && !deep && !dv.vote_shadow;
     dv.wave_rays = 256;
     if (const char* e = getenv("PT_WAVE_RAYS")) {
         uint32_t r = (uint32_t)atoi(e);
@@ -751,9 +752,13 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
                               push, r.ln->sq, spush, r.ls, r.st);
         }
         if (nee && bounce < P->max_bounces) {
-            Timer t(s, r.st, PT_K_SHADOW);
-            uint32_t* cursors = s->persistent ? r.ln->counters + (3 * kCounterSets + bounce) * kSetWords : nullptr;
-            ptd::launch_shadow(s->dev, r.ln->sq, ptd::Live{spush.counts, r.seg, r.cap, cursors}, r.ls, ctr, r.st);
+            if (fused && s->dev.fuse_shadow) {  // traced inside the path kernel; only their count is left
+                ptd::launch_count_shadow_rays(spush.counts, ctr, r.st);
+            } else {
+                Timer t(s, r.st, PT_K_SHADOW);
+                uint32_t* cursors = s->persistent ? r.ln->counters + (3 * kCounterSets + bounce) * kSetWords : nullptr;
+                ptd::launch_shadow(s->dev, r.ln->sq, ptd::Live{spush.counts, r.seg, r.cap, cursors}, r.ls, ctr, r.st);
+            }
         }
     };
 

@@ -127,6 +127,7 @@ struct Scene {
     // scheduled ranges of wave_rays rays per wave, or one ray per lane
     uint8_t vote_primary, vote_secondary, vote_shadow;
     uint8_t fuse;  // extend + shade of a bounce in one kernel where its rays go one per lane
+    uint8_t fuse_shadow;  // ... and the bounce's light sample traced in that kernel too (shallow trees)
     uint32_t wave_rays;
     uint32_t n_cu;  // compute units of the device (size of a persistent launch)
     Camera cam;
@@ -259,6 +260,9 @@ bool launch_path(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, Li
                  ShadowQueue sq, Push sq_push, Sample3 lsample, Counters* ctr, hipStream_t st);
 // lsample.c covers every frame of the batch; frames [0, split) have their bits in lsample.lit, the
 // rest (the second lane's) in lit1, both indexed from the lane's first frame
+// the fused path kernel traced its own shadow rays (Scene::fuse_shadow) and left their number in the
+// segment counters of the shadow queue it did not fill: add them to the statistics
+void launch_count_shadow_rays(const uint32_t* seg_counts, Counters* ctr, hipStream_t st);
 void launch_accumulate(const Frame& fr, Sample3 lsample, const unsigned long long* lit1, uint32_t split, double* accum,
                        Counters* ctr /* nullptr: no statistics */, hipStream_t st);
 // parity entry points

@@ -1491,6 +1491,22 @@ __global__ __launch_bounds__(PathBlock<DEPTH>::value) void k_path(Scene sc, Fram
             uint32_t leaf = (FIRST && sc.eye_nodes) ? traverse_eye<DEPTH, kPathBlock>(sc, d, 1e-5, t, stack + threadIdx.x)
                                                     : traverse<DEPTH, false, false, kPathBlock>(sc, o, d, 1e-5, t, stack + threadIdx.x, nn, nt);
             shade_vertex<FIRST, LAST, NEE, PLAIN, true>(sc, fr, bounce, in, i, rec, leaf, t, o, d, ls, r);
+            if (NEE && !LAST && sc.fuse_shadow && r.shadow) {
+                // the light sample's visibility, in place: the shadow ray never leaves the registers
+                // (84 B written + read per shadow ray and one launch per bounce otherwise).  Same order
+                // of additions as the shadow kernel's: the vertex's emission first, then its light sample.
+                double st_max = r.s_tmax;
+                uint32_t nn2 = 0, nt2 = 0;
+                if (traverse<DEPTH, true, false, kPathBlock>(sc, r.n_o, r.s_d, 1e-5, st_max, stack + threadIdx.x, nn2, nt2) == PT_MISS) {
+                    if (FIRST) {
+                        double* c = ls.c + (size_t)r.slot * 3;
+                        if (r.lit) { c[0] += r.s_c.x; c[1] += r.s_c.y; c[2] += r.s_c.z; }
+                        else { c[0] = 0. + r.s_c.x; c[1] = 0. + r.s_c.y; c[2] = 0. + r.s_c.z; r.lit = true; }
+                    } else {
+                        radiance_add(ls, r.slot, r.s_c);
+                    }
+                }
+            }
         }
         if (FIRST) store_lit(ls, i - (threadIdx.x & 63u), end, r.lit);
         if (!sparse) break;
@@ -1501,9 +1517,10 @@ __global__ __launch_bounds__(PathBlock<DEPTH>::value) void k_path(Scene sc, Fram
                                                                    : compact_slot<kPathBlock>(r.alive, out_push.counts + region * kCtrStride, lds_a));
     if (r.alive) push_path<NEE>(out, pos, r);
     if (NEE) {
+        // (fuse_shadow: only the count is kept, for the statistics)
         uint32_t spos = region * sq_push.seg_size + (kPathBlock == 64 ? compact_wave(r.shadow, sq_push.counts + region * kCtrStride)
                                                                       : compact_slot<kPathBlock>(r.shadow, sq_push.counts + region * kCtrStride, lds_b));
-        if (r.shadow) push_shadow(sq, spos, r);
+        if (r.shadow && !sc.fuse_shadow) push_shadow(sq, spos, r);
     }
 }
 
@@ -1738,6 +1755,15 @@ void launch_shadow(const Scene& sc, ShadowQueue sq, Live live, Sample3 ls, Count
     if (!live.n) return;
     if (sc.vote_shadow) launch_shadow_v<true>(sc, sq, live, sc.wave_rays, ls, ctr, st);
     else launch_shadow_v<false>(sc, sq, live, 64, ls, ctr, st);
+}
+__global__ void k_count_shadow_rays(const uint32_t* seg_counts, Counters* ctr) {
+    unsigned long long n = seg_counts[threadIdx.x * kCtrStride];  // kSegs threads
+#pragma unroll
+    for (int d = 32; d; d >>= 1) n += __shfl_down(n, d);
+    if (threadIdx.x == 0 && n) atomicAdd(&ctr->shadow_rays, n);
+}
+void launch_count_shadow_rays(const uint32_t* seg_counts, Counters* ctr, hipStream_t st) {
+    hipLaunchKernelGGL(k_count_shadow_rays, dim3(1), dim3(kSegs), 0, st, seg_counts, ctr);
 }
 void launch_accumulate(const Frame& fr, Sample3 ls, const unsigned long long* lit1, uint32_t split, double* accum,
                        Counters* ctr, hipStream_t st) {
