@@ -573,9 +573,11 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
     if (const char* e = getenv("PT_PERSISTENT")) s->persistent = atoi(e) != 0;
     s->pipeline = dv.bvh_depth > 8;
     if (const char* e = getenv("PT_PIPELINE")) s->pipeline = atoi(e) != 0;  // tuning / tests, like the above
-    dv.plain = 1;
-    for (uint32_t i = 0; i < d->n_mats; ++i)
-        if (d->mats[i].kind != PT_MAT_LAMBERT || d->mats[i].tex >= 0) dv.plain = 0;
+    dv.mat_features = 0;
+    for (uint32_t i = 0; i < d->n_mats; ++i) {
+        if (d->mats[i].tex >= 0) dv.mat_features |= 1u;
+        if (d->mats[i].kind != PT_MAT_LAMBERT) dv.mat_features |= 2u;
+    }
     dv.light_area = acc;
     // scene.rs:38-42, hoisted out of Camera::ray
     H3 view{d->camera.view[0], d->camera.view[1], d->camera.view[2]};

@@ -122,7 +122,8 @@ struct Scene {
     uint32_t n_prims;
     uint32_t n_nodes, n_tris, n_lights, bvh_depth;
     double light_area;
-    uint32_t plain;  // only untextured Lambertian materials (selects the lean shade kernel)
+    uint32_t mat_features;  // bit 0: some material has a texture; bit 1: some is Glossy / Mirror / Transparent
+                            // (selects the shade code compiled in: 0 = the lean untextured-Lambertian kernels)
     // traversal scheduling, resolved at scene creation (pt_api.cpp resolve_scheduling): vote-
     // scheduled ranges of wave_rays rays per wave, or one ray per lane
     uint8_t vote_primary, vote_secondary, vote_shadow;

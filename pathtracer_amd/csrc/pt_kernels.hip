@@ -1157,7 +1157,9 @@ __global__ void k_build_emitters(Scene sc, const uint32_t* leaf, uint32_t n, Emi
 //   LAST  = bounce == max_bounces: only main.rs:299/307 remain (the reference still samples the
 //           BRDF there, main.rs:310, but nothing consumes it), so the ray and hit distance are not
 //           even loaded unless NEE needs them for the MIS weight.
-//   PLAIN = the scene has only untextured Lambertian materials: the Glossy and texture code is
+//   MATS  = which material code the scene needs (Scene::mat_features): bit 0 textures, bit 1
+//           Glossy / Mirror / Transparent.  0 ("plain") =
+//           the scene has only untextured Lambertian materials: the Glossy and texture code is
 //           compiled out, which is what keeps this kernel's register count (and occupancy) sane.
 //   FUSED = o, d hold the ray (the caller traced it); otherwise they are loaded here when needed.
 struct ShadeOut {
@@ -1184,10 +1186,11 @@ __device__ __forceinline__ PathRec load_rec(const Queue& in, uint32_t i) {
 //   DIFFS = PT_FLAG_PROPAGATE_DIFFS (with USE_DIFFS, on a scene with textures): rays carry their
 //           differential rays through the queue (Queue::diff) and every vertex spawns them as the
 //           legacy reflect_diff / refract_diff do.
-template <bool FIRST, bool LAST, bool NEE, bool PLAIN, bool FUSED, bool DIFFS = false>
+template <bool FIRST, bool LAST, bool NEE, int MATS, bool FUSED, bool DIFFS = false>
 __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, uint32_t bounce, const Queue& in,
                                              uint32_t i, PathRec rec, uint32_t leaf, double t_hit, D3 o, D3 d,
                                              const Sample3& ls, ShadeOut& r) {
+    constexpr bool TEX = (MATS & 1) != 0, SPEC = (MATS & 2) != 0;
     const uint32_t slot = rec.slot;
     r.slot = slot;
     uint32_t s = fdiv(slot, fr.div_pixels), p = slot - s * fr.n_tile_pixels;
@@ -1212,7 +1215,7 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
         add = T * ld3(sc.background);  // main.rs:299
     } else if (!kNeedRay) {
         const Material& m = sc.mats[hit_material(sc, leaf)];
-        D3 le = (!PLAIN && m.kind != PT_MAT_LAMBERT) ? mk(0., 0., 0.) : ld3(m.emission);  // microfacet.rs:33-35; specular: none
+        D3 le = (SPEC && m.kind != PT_MAT_LAMBERT) ? mk(0., 0., 0.) : ld3(m.emission);  // microfacet.rs:33-35; specular: none
         add = T * le;  // main.rs:307
     } else {
         const double t = t_hit;
@@ -1220,7 +1223,7 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
         D3 position, normal;
         hit_geometry(sc, leaf, o, d, t, mat, position, normal);
         const Material& m = sc.mats[mat];
-        D3 le = (!PLAIN && m.kind != PT_MAT_LAMBERT) ? mk(0., 0., 0.) : ld3(m.emission);  // microfacet.rs:33-35; specular: none
+        D3 le = (SPEC && m.kind != PT_MAT_LAMBERT) ? mk(0., 0., 0.) : ld3(m.emission);  // microfacet.rs:33-35; specular: none
         add = T * le;  // main.rs:307
         if (NEE && !FIRST && (le.x != 0. || le.y != 0. || le.z != 0.)) {
             // MIS weight of a BRDF-sampled hit on a light (balance heuristic)
@@ -1254,8 +1257,9 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
                 if (m.kind == PT_MAT_LAMBERT)
                     diffuse = m.tex < 0 ? ld3(m.color)
                                         : textured_color(sc, m, load_tri(sc, leaf), leaf, o, d, normal, has_dp, dpdx, dpdy);
-            } else if (PLAIN) diffuse = ld3(m.color);
-            else if (m.kind == PT_MAT_LAMBERT) diffuse = diffuse_of(sc, m, leaf, o, d, position, normal, fr, FIRST, pixel, s);
+            } else if (!SPEC || m.kind == PT_MAT_LAMBERT) {
+                diffuse = TEX ? diffuse_of(sc, m, leaf, o, d, position, normal, fr, FIRST, pixel, s) : ld3(m.color);
+            }
             if (NEE && sc.n_lights) {
                 double r0, r1;
                 uniform2(fr.seed, pixel, sample, bounce, STREAM_LIGHT, r0, r1);
@@ -1289,10 +1293,10 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
                 D3 wl = diff / dist;
                 D3 wo = -d;
                 double p_b;
-                if ((!PLAIN && is_glossy(m.kind))) {
+                if ((SPEC && is_glossy(m.kind))) {
                     double pg = glossy_pdf_dir(m.width, wo, wl, normal, m.kind == PT_MAT_GLOSSY_GGX);
                     p_b = pg > 0. ? pg : 0.;
-                } else if (!PLAIN && m.kind != PT_MAT_LAMBERT) {
+                } else if (SPEC && m.kind != PT_MAT_LAMBERT) {
                     p_b = 0.;  // specular: a light sample has zero weight
                 } else {
                     double c = dot(normal, wl);
@@ -1301,7 +1305,7 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
                 double cos_l = L.sphere ? dot(sphere_n, -wl) : fabs(dot(ld3(L.normal), wl));
                 double p_l = cos_l <= 0. ? 0. : dist * dist / (sc.light_area * cos_l);
                 if (p_l > 0. && p_b > 0. && dist > 0.) {
-                    D3 f = (!PLAIN && is_glossy(m.kind)) ? glossy_f(m.width, ld3(m.color), wo, wl, normal, m.kind == PT_MAT_GLOSSY_GGX)
+                    D3 f = (SPEC && is_glossy(m.kind)) ? glossy_f(m.width, ld3(m.color), wo, wl, normal, m.kind == PT_MAT_GLOSSY_GGX)
                                                    : diffuse * PT_FRAC_1_PI;
                     double cosn = fabs(dot(wl, normal));
                     double wgt = p_l / (p_l + p_b);
@@ -1315,7 +1319,7 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
             // Russian roulette of the legacy integrator (main.rs:85-93,110): trace_depth = bounce + 1
             double luminance = 1.;
             bool absorbed = false;
-            if ((fr.flags & PT_FLAG_RUSSIAN_ROULETTE) && bounce + 1 >= 5 && (PLAIN || m.kind == PT_MAT_LAMBERT)) {
+            if ((fr.flags & PT_FLAG_RUSSIAN_ROULETTE) && bounce + 1 >= 5 && (!SPEC || m.kind == PT_MAT_LAMBERT)) {
                 luminance = (diffuse.x + diffuse.y + diffuse.z) / 3.;
                 double q0, q1;
                 uniform2(fr.seed, pixel, sample, bounce, STREAM_ROULETTE, q0, q1);
@@ -1325,12 +1329,12 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
                 double xi1, xi2;
                 uniform2(fr.seed, pixel, sample, bounce, STREAM_BRDF, xi1, xi2);
                 int lobe = 0;
-                if (!PLAIN && (m.kind == PT_MAT_MIRROR || m.kind == PT_MAT_TRANSPARENT)) {
+                if (SPEC && (m.kind == PT_MAT_MIRROR || m.kind == PT_MAT_TRANSPARENT)) {
                     r.n_T = T;  // specular: radiance passes unchanged
                     r.n_d = specular_sample(m, d, normal, xi1, lobe);
                     r.n_pdf = -1.;
                 } else {
-                    Brdf bs = (!PLAIN && is_glossy(m.kind)) ? glossy_sample(m.width, ld3(m.color), d, normal, xi1, xi2, m.kind == PT_MAT_GLOSSY_GGX)
+                    Brdf bs = (SPEC && is_glossy(m.kind)) ? glossy_sample(m.width, ld3(m.color), d, normal, xi1, xi2, m.kind == PT_MAT_GLOSSY_GGX)
                                                       : lambertian_sample(diffuse, normal, xi1, xi2);
                     r.n_T = T * (bs.f * fabs(dot(bs.wi, normal)) / bs.pdf);  // main.rs:311
                     r.n_d = bs.wi;
@@ -1388,7 +1392,7 @@ __device__ __forceinline__ void push_shadow(const ShadowQueue& sq, uint32_t spos
 }
 
 // shade: one lane per live path.
-template <bool FIRST, bool LAST, bool NEE, bool PLAIN, bool DIFFS = false>
+template <bool FIRST, bool LAST, bool NEE, int MATS, bool DIFFS = false>
 __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t bounce, Queue in, Hits hits,
                                                   Live live, Queue out, Push out_push, ShadowQueue sq, Push sq_push,
                                                   Sample3 ls) {
@@ -1403,7 +1407,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
             ShadeOut r;
             uint32_t leaf = hits.tri[i];
             double t = (leaf != PT_MISS && NEE) ? hits.t[i] : 0.;
-            shade_vertex<FIRST, LAST, NEE, PLAIN, false, DIFFS>(sc, fr, bounce, in, i, load_rec<FIRST>(in, i), leaf, t,
+            shade_vertex<FIRST, LAST, NEE, MATS, false, DIFFS>(sc, fr, bounce, in, i, load_rec<FIRST>(in, i), leaf, t,
                                                                 mk(0., 0., 0.), mk(0., 0., 0.), ls, r);
         }
     }
@@ -1418,7 +1422,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
         uint32_t leaf = hits.tri[i];
         // the hit distance is only needed (and only loaded) where the vertex is shaded in full
         double t = (leaf != PT_MISS && (!LAST || NEE)) ? hits.t[i] : 0.;
-        shade_vertex<FIRST, LAST, NEE, PLAIN, false, DIFFS>(sc, fr, bounce, in, i, load_rec<FIRST>(in, i), leaf, t,
+        shade_vertex<FIRST, LAST, NEE, MATS, false, DIFFS>(sc, fr, bounce, in, i, load_rec<FIRST>(in, i), leaf, t,
                                                             mk(0., 0., 0.), mk(0., 0., 0.), ls, r);
     }
     if (FIRST) store_lit(ls, i - (threadIdx.x & 63u), n, r.lit);
@@ -1445,7 +1449,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
 #define PT_PATH_BLOCK_DEEP 64
 #endif
 template <int DEPTH> struct PathBlock { static constexpr int value = DEPTH <= 8 ? 128 : PT_PATH_BLOCK_DEEP; };
-template <int DEPTH, bool FIRST, bool LAST, bool NEE, bool PLAIN>
+template <int DEPTH, bool FIRST, bool LAST, bool NEE, int MATS>
 __global__ __launch_bounds__(PathBlock<DEPTH>::value) void k_path(Scene sc, Frame fr, uint32_t bounce, Queue in, Live live, Queue out,
                                                  Push out_push, ShadowQueue sq, Push sq_push, Sample3 ls,
                                                  Counters* ctr) {
@@ -1490,7 +1494,7 @@ __global__ __launch_bounds__(PathBlock<DEPTH>::value) void k_path(Scene sc, Fram
             uint32_t nn = 0, nt = 0;
             uint32_t leaf = (FIRST && sc.eye_nodes) ? traverse_eye<DEPTH, kPathBlock>(sc, d, 1e-5, t, stack + threadIdx.x)
                                                     : traverse<DEPTH, false, false, kPathBlock>(sc, o, d, 1e-5, t, stack + threadIdx.x, nn, nt);
-            shade_vertex<FIRST, LAST, NEE, PLAIN, true>(sc, fr, bounce, in, i, rec, leaf, t, o, d, ls, r);
+            shade_vertex<FIRST, LAST, NEE, MATS, true>(sc, fr, bounce, in, i, rec, leaf, t, o, d, ls, r);
             if (NEE && !LAST && sc.fuse_shadow && r.shadow) {
                 // the light sample's visibility, in place: the shadow ray never leaves the registers
                 // (84 B written + read per shadow ray and one launch per bounce otherwise).  Same order
@@ -1672,16 +1676,20 @@ template <bool FIRST, bool LAST>
 static void launch_shade_t(bool nee, dim3 g, dim3 b, hipStream_t st, const Scene& sc, const Frame& fr, uint32_t bounce,
                            Queue in, Hits hits, Live live, Queue out, Push out_push, ShadowQueue sq, Push sq_push,
                            Sample3 ls) {
-    if ((fr.flags & PT_FLAG_PROPAGATE_DIFFS) && !sc.plain) {  // the host sets the flag only where it has an effect
-        if (nee) hipLaunchKernelGGL((k_shade<FIRST, LAST, true, false, true>), g, b, 0, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls);
-        else hipLaunchKernelGGL((k_shade<FIRST, LAST, false, false, true>), g, b, 0, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls);
-    } else if (sc.plain) {
-        if (nee) hipLaunchKernelGGL((k_shade<FIRST, LAST, true, true>), g, b, 0, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls);
-        else hipLaunchKernelGGL((k_shade<FIRST, LAST, false, true>), g, b, 0, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls);
-    } else {
-        if (nee) hipLaunchKernelGGL((k_shade<FIRST, LAST, true, false>), g, b, 0, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls);
-        else hipLaunchKernelGGL((k_shade<FIRST, LAST, false, false>), g, b, 0, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls);
+#define PT_SHADE(N, M, D) hipLaunchKernelGGL((k_shade<FIRST, LAST, N, M, D>), g, b, 0, st, sc, fr, bounce, in, hits, live, out, out_push, sq, sq_push, ls)
+    const bool diffs = (fr.flags & PT_FLAG_PROPAGATE_DIFFS) && (sc.mat_features & 1u);  // the host sets the flag only where it has an effect
+    switch (sc.mat_features & 3u) {
+        case 0: if (nee) PT_SHADE(true, 0, false); else PT_SHADE(false, 0, false); break;
+        case 1:
+            if (diffs) { if (nee) PT_SHADE(true, 1, true); else PT_SHADE(false, 1, true); }
+            else { if (nee) PT_SHADE(true, 1, false); else PT_SHADE(false, 1, false); }
+            break;
+        case 2: if (nee) PT_SHADE(true, 2, false); else PT_SHADE(false, 2, false); break;
+        default:
+            if (diffs) { if (nee) PT_SHADE(true, 3, true); else PT_SHADE(false, 3, true); }
+            else { if (nee) PT_SHADE(true, 3, false); else PT_SHADE(false, 3, false); }
     }
+#undef PT_SHADE
 }
 void launch_shade(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, Hits hits, Live live, Queue out,
                   Push out_push, ShadowQueue sq, Push sq_push, Sample3 ls, hipStream_t st) {
@@ -1702,13 +1710,14 @@ template <int DEPTH, bool FIRST, bool LAST>
 static void launch_path_t(bool nee, dim3 g, dim3 b, hipStream_t st, const Scene& sc, const Frame& fr, uint32_t bounce,
                           Queue in, Live live, Queue out, Push out_push, ShadowQueue sq, Push sq_push, Sample3 ls,
                           Counters* ctr) {
-    if (sc.plain) {
-        if (nee) hipLaunchKernelGGL((k_path<DEPTH, FIRST, LAST, true, true>), g, b, 0, st, sc, fr, bounce, in, live, out, out_push, sq, sq_push, ls, ctr);
-        else hipLaunchKernelGGL((k_path<DEPTH, FIRST, LAST, false, true>), g, b, 0, st, sc, fr, bounce, in, live, out, out_push, sq, sq_push, ls, ctr);
-    } else {
-        if (nee) hipLaunchKernelGGL((k_path<DEPTH, FIRST, LAST, true, false>), g, b, 0, st, sc, fr, bounce, in, live, out, out_push, sq, sq_push, ls, ctr);
-        else hipLaunchKernelGGL((k_path<DEPTH, FIRST, LAST, false, false>), g, b, 0, st, sc, fr, bounce, in, live, out, out_push, sq, sq_push, ls, ctr);
+#define PT_PATHK(N, M) hipLaunchKernelGGL((k_path<DEPTH, FIRST, LAST, N, M>), g, b, 0, st, sc, fr, bounce, in, live, out, out_push, sq, sq_push, ls, ctr)
+    switch (sc.mat_features & 3u) {
+        case 0: if (nee) PT_PATHK(true, 0); else PT_PATHK(false, 0); break;
+        case 1: if (nee) PT_PATHK(true, 1); else PT_PATHK(false, 1); break;
+        case 2: if (nee) PT_PATHK(true, 2); else PT_PATHK(false, 2); break;
+        default: if (nee) PT_PATHK(true, 3); else PT_PATHK(false, 3);
     }
+#undef PT_PATHK
 }
 // The fused form exists where a bounce is traced one ray per lane: every bounce of a shallow tree
 // (the 8-entry stack instantiation) and the primary bounce of any tree.
