@@ -207,7 +207,7 @@ void resolve_scheduling(ptd::Scene& dv) {
     dv.vote_secondary = flag("PT_TRAV_VOTE", deep);
     dv.vote_shadow = flag("PT_TRAV_VOTE_SHADOW", deep);
     dv.fuse = flag("PT_FUSE", true);
-    dv.fuse_shadow = flag("PT_FUSE_SHADOW", true) && dv.fuse && !deep && !dv.vote_shadow;
+    dv.fuse_shadow = flag("PT_FUSE_SHADOW", true) && dv.fuse;
     dv.wave_rays = 256;
     if (const char* e = getenv("PT_WAVE_RAYS")) {
         uint32_t r = (uint32_t)atoi(e);

@@ -128,7 +128,7 @@ struct Scene {
     // scheduled ranges of wave_rays rays per wave, or one ray per lane
     uint8_t vote_primary, vote_secondary, vote_shadow;
     uint8_t fuse;  // extend + shade of a bounce in one kernel where its rays go one per lane
-    uint8_t fuse_shadow;  // ... and the bounce's light sample traced in that kernel too (shallow trees)
+    uint8_t fuse_shadow;  // ... and the bounce's light sample traced in that kernel too
     uint32_t wave_rays;
     uint32_t n_cu;  // compute units of the device (size of a persistent launch)
     Camera cam;
