@@ -176,7 +176,9 @@ def main():
         rec, hit = 76.0, 12.0
         P = float(samples_per_rank)                 # primary rays of the timed region
         lit = P * st2["lit_samples"] / max(1, st2["samples"])   # samples that gathered radiance
-        S = max(0.0, float(st["rays"]) - P)         # secondary rays == records written
+        # primary rays actually traced (those through pixels outside the scene's screen bounds are not)
+        P_traced = P * st0["rays"] / max(1, st0["samples"])
+        S = max(0.0, float(st["rays"]) - P_traced)  # secondary rays == records written
         scene_all = float(st["rays"]) * scene_ray
         per_kind = {
             "extend": P * hit + S * (48.0 + hit),
@@ -189,7 +191,7 @@ def main():
         # which kernel walked the tree for which rays: the fused path kernel every bounce of a shallow
         # tree, or only the primary bounce of a deep one (the extend kernel then has the secondary rays)
         if kern["path"]["launches"] and kern["extend"]["launches"]:
-            scene_primary = P * (32.0 * V0 + 36.0 * T0)
+            scene_primary = P_traced * (32.0 * V0 + 36.0 * T0)
             scene_of = {"path": scene_primary, "extend": scene_all - scene_primary}
             # deep tree: path = primary bounce only (writes the records of the secondary rays), extend and
             # shade = the secondary rays (records written by shade: the few survivors of the cull, ignored)
@@ -231,7 +233,7 @@ def main():
             "nodes_per_ray": round(V, 3), "tris_per_ray": round(T, 3),
             "nodes_per_primary_ray": round(V0, 3), "tris_per_primary_ray": round(T0, 3),
             "rays_per_sample": round(st["rays"] / max(1, samples_per_rank), 4),
-            "lit_samples": round(lit / P, 4),
+            "lit_samples": round(lit / P, 4), "primary_rays_traced": round(P_traced / P, 4),
             "kernel_ms": {k: round(v["ms"], 3) for k, v in kern.items()},
             "kernel_launches": {k: v["launches"] for k, v in kern.items()},
             "kernel_share": {k: round(v["ms"] / total_kernel_ms, 4) for k, v in kern.items()} if total_kernel_ms else {},

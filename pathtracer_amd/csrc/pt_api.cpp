@@ -167,6 +167,7 @@ struct pt_scene {
     std::vector<hipEvent_t> event_pool;
     int pipeline = 0;               // 0: one lane; 1: two lanes on two streams (see Lane)
     int persistent = 1;             // vote-scheduled launches claim their ranges from work cursors
+    int screen_cull = 1;            // primary rays outside the scene's screen bounds are not generated
     hipStream_t side = nullptr;     // the second lane's stream
     std::vector<hipEvent_t> sync;   // cross-stream ordering events (no timing)
     ~pt_scene() {
@@ -571,6 +572,7 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
         dv.n_cu = (uint32_t)prop.multiProcessorCount;
     }
     if (const char* e = getenv("PT_PERSISTENT")) s->persistent = atoi(e) != 0;
+    if (const char* e = getenv("PT_SCREEN_CULL")) s->screen_cull = atoi(e) != 0;
     s->pipeline = dv.bvh_depth > 8;
     if (const char* e = getenv("PT_PIPELINE")) s->pipeline = atoi(e) != 0;  // tuning / tests, like the above
     dv.mat_features = 0;
@@ -668,6 +670,47 @@ int pt_get_stats(pt_scene* s, pt_stats* out) {
     *out = s->stats;
     return PT_OK;
 }
+
+namespace {
+// Frame::cx0..cy1: the pixels whose primary rays can reach the scene at all.  The root box's corners
+// are projected through Camera::ray's own parametrisation (dir ~ view_dir + a0 x + a1 y, scene.rs:38-43;
+// pixel <-> x, y as main.rs:412-424) and the rectangle grown by two pixels (the frame jitter moves a
+// ray by a quarter pixel at most).  A corner beside or behind the eye, an analytic primitive or the
+// environment PT_SCREEN_CULL=0 give the whole image.
+void screen_bounds(const pt_scene* s, uint32_t width, uint32_t height, ptd::Frame& fr) {
+    fr.cx0 = 0; fr.cy0 = 0; fr.cx1 = width; fr.cy1 = height;
+    if (!s->screen_cull || s->dev.n_prims) return;
+    if (s->nodes.empty() || s->n_tris == 0) { fr.cx1 = 0; fr.cy1 = 0; return; }   // nothing to hit
+    const float* b = s->nodes[0].bounds;   // both children's boxes: lo xyz, hi xyz each
+    double lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = b[a]; hi[a] = b[3 + a];
+        if (s->nodes[0].child[1] != PT_BVH_EMPTY) { lo[a] = std::fmin(lo[a], (double)b[6 + a]); hi[a] = std::fmax(hi[a], (double)b[9 + a]); }
+    }
+    const ptd::Camera& c = s->dev.cam;
+    const double vv = c.view_dir[0] * c.view_dir[0] + c.view_dir[1] * c.view_dir[1] + c.view_dir[2] * c.view_dir[2];
+    const double aspect = (double)width / (double)height;
+    double px0 = 1e300, px1 = -1e300, py0 = 1e300, py1 = -1e300;
+    for (int k = 0; k < 8; ++k) {
+        const double v[3] = {((k & 1) ? hi[0] : lo[0]) - c.eye[0], ((k & 2) ? hi[1] : lo[1]) - c.eye[1], ((k & 4) ? hi[2] : lo[2]) - c.eye[2]};
+        const double vz = v[0] * c.view_dir[0] + v[1] * c.view_dir[1] + v[2] * c.view_dir[2];
+        const double len = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        if (!(vz > 1e-3 * len * std::sqrt(vv))) return;   // beside / behind the eye (or NaN): no bound
+        const double x = (v[0] * c.axes0[0] + v[1] * c.axes0[1] + v[2] * c.axes0[2]) * vv / vz;
+        const double y = (v[0] * c.axes1[0] + v[1] * c.axes1[1] + v[2] * c.axes1[2]) * vv / vz;
+        const double px = (x / aspect + 1.) * 0.5 * (double)width - 0.5;
+        const double py = (1. - y) * 0.5 * (double)height - 0.5;
+        px0 = std::fmin(px0, px); px1 = std::fmax(px1, px);
+        py0 = std::fmin(py0, py); py1 = std::fmax(py1, py);
+    }
+    if (!(px0 <= px1 && py0 <= py1)) return;
+    auto clampi = [](double v, uint32_t n) { return (uint32_t)std::fmin(std::fmax(v, 0.), (double)n); };
+    fr.cx0 = clampi(std::floor(px0) - 2., width);
+    fr.cx1 = clampi(std::ceil(px1) + 3., width);
+    fr.cy0 = clampi(std::floor(py0) - 2., height);
+    fr.cy1 = clampi(std::ceil(py1) + 3., height);
+}
+}  // namespace
 
 int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, void* stream) {
     if (!s || !accum_dev) { set_error("null argument"); return PT_ERR_INVALID; }
@@ -777,6 +820,7 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
         fr.flags = diffs ? P->flags : (P->flags & ~(uint32_t)PT_FLAG_PROPAGATE_DIFFS);
         fr.diff_size = P->diff_size;
         fr.jitter = w.jitter.as<double>() + (size_t)b0 * 2;
+        screen_bounds(s, P->width, P->height, fr);
         ptd::finish_frame(fr);
         // the generate stage is fused into the bounce-0 extend and shade kernels (they rebuild the
         // camera ray from the pixel): no primary-ray queue is written or read.

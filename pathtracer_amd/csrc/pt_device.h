@@ -221,10 +221,15 @@ struct Frame {  // per-call constants of generate / shade
     // Slot order inside a frame: 8x8-pixel blocks (a wave's 64 primary rays cover a square, not a
     // 64x1 strip: they walk the same part of the tree), then the strip right of the last whole block
     // column, then the rows below the last whole block row, both row by row.
+    // Screen bounds of the scene: a primary ray through a pixel outside [cx0, cx1) x [cy0, cy1) cannot
+    // hit anything (the projection of the root box, two pixels of margin; the whole image when the
+    // eye is inside or beside the box), so such a lane skips the camera ray and the tree.
+    uint32_t cx0, cy0, cx1, cy1;
+    uint32_t n_on_screen;            // pixels of the tile inside those bounds (the primary rays actually traced, per frame)
     uint32_t w8, h8, n8, bw, rw;     // tile_w & ~7, tile_h & ~7, w8 * h8, w8 / 8, tile_w - w8 (0 -> 1 for the divisor)
     FastDiv div_bw, div_rw;
 };
-inline void finish_frame(Frame& fr) {
+inline void finish_frame(Frame& fr) {  // (cx0..cy1 are set by the caller; default: no culling)
     fr.div_pixels = make_fastdiv(fr.n_tile_pixels ? fr.n_tile_pixels : 1u);
     fr.div_tile_w = make_fastdiv(fr.tile_w ? fr.tile_w : 1u);
     fr.aspect = (double)fr.width / (double)fr.height;
@@ -235,6 +240,11 @@ inline void finish_frame(Frame& fr) {
     fr.rw = fr.tile_w - fr.w8;
     fr.div_bw = make_fastdiv(fr.bw ? fr.bw : 1u);
     fr.div_rw = make_fastdiv(fr.rw ? fr.rw : 1u);
+    auto overlap = [](uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1) {
+        uint32_t lo = a0 > b0 ? a0 : b0, hi = a1 < b1 ? a1 : b1;
+        return hi > lo ? hi - lo : 0u;
+    };
+    fr.n_on_screen = overlap(fr.x0, fr.x0 + fr.tile_w, fr.cx0, fr.cx1) * overlap(fr.y0, fr.y0 + fr.tile_h, fr.cy0, fr.cy1);
 }
 
 struct Counters {  // device-side statistics (pt_stats)

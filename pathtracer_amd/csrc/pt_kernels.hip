@@ -576,7 +576,8 @@ __global__ __launch_bounds__(kTravBlock) void k_extend(Scene sc, Frame fr, Queue
                                                    const double* __restrict__ tmax, Live live, uint32_t wave_rays,
                                                    Hits hits, Counters* ctr) {
     __shared__ int stack[DEPTH * kTravBlock];
-    if (ctr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->rays, live_total(live));
+    if (ctr && blockIdx.x == 0 && threadIdx.x == 0)
+        atomicAdd(&ctr->rays, PRIMARY ? (unsigned long long)fr.n_on_screen * fr.n_samples : live_total(live));
     // wave w of the launch owns the wave_rays queue entries [w, w + 1) * wave_rays
     const uint32_t wib = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t block_rays = wave_rays * (kTravBlock / 64);
@@ -606,9 +607,14 @@ __global__ __launch_bounds__(kTravBlock) void k_extend(Scene sc, Frame fr, Queue
                 uint32_t s = fdiv(i, fr.div_pixels), p = i - s * fr.n_tile_pixels;
                 uint32_t ty, tx;
                 slot_pixel(fr, p, tx, ty);
-                PixelArgs a = pixel_args(fr.x0 + tx, fr.y0 + ty, fr.width, fr.height, fr.jitter[2 * s], fr.jitter[2 * s + 1], fr.aspect);
+                const uint32_t gx = fr.x0 + tx, gy = fr.y0 + ty;
+                PixelArgs a = pixel_args(gx, gy, fr.width, fr.height, fr.jitter[2 * s], fr.jitter[2 * s + 1], fr.aspect);
                 o = ld3(sc.cam.eye);
                 d = camera_dir(sc.cam, a.x, a.y);
+                t_min = 1e-5;
+                // outside the scene's screen bounds (Frame::cx0..): an empty t range, nothing can be hit
+                t_max = (gx >= fr.cx0 && gx < fr.cx1 && gy >= fr.cy0 && gy < fr.cy1) ? 1.7976931348623157e308 : -1.;
+                return;
             } else {
                 o = mk(q.o[0][i], q.o[1][i], q.o[2][i]);
                 d = mk(q.d[0][i], q.d[1][i], q.d[2][i]);
@@ -633,7 +639,8 @@ __global__ __launch_bounds__(kTravBlock) void k_extend(Scene sc, Frame fr, Queue
         D3 o, d;
         double t_min, t_max;
         fetch(i, o, d, t_min, t_max);
-        done(i, traverse<DEPTH, false, STATS>(sc, o, d, t_min, t_max, stack + threadIdx.x, nn, nt), t_max);
+        if (PRIMARY && t_max < 0.) done(i, PT_MISS, t_max);  // off screen
+        else done(i, traverse<DEPTH, false, STATS>(sc, o, d, t_min, t_max, stack + threadIdx.x, nn, nt), t_max);
     }
     if (STATS) {
         // wave-level reduction, one atomic pair per wave
@@ -1457,7 +1464,8 @@ __global__ __launch_bounds__(PathBlock<DEPTH>::value) void k_path(Scene sc, Fram
     __shared__ int stack[DEPTH * kPathBlock];
     __shared__ uint32_t lds_a[kPathBlock / 64 + 1];
     __shared__ uint32_t lds_b[kPathBlock / 64 + 1];
-    if (ctr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->rays, live_total(live));
+    if (ctr && blockIdx.x == 0 && threadIdx.x == 0)
+        atomicAdd(&ctr->rays, FIRST ? (unsigned long long)fr.n_on_screen * fr.n_samples : live_total(live));
     ShadeOut r;
     r.n_o = r.n_d = r.n_T = r.s_d = r.s_c = mk(0., 0., 0.);
     const bool sparse = LAST && !FIRST && live.counts && live.sparse;
@@ -1477,14 +1485,19 @@ __global__ __launch_bounds__(PathBlock<DEPTH>::value) void k_path(Scene sc, Fram
         if (begin >= end) return;
         const uint32_t i = begin + threadIdx.x;
         if (i < end) {
-            D3 o, d;
+            D3 o = mk(0., 0., 0.), d = o;
+            bool on_screen = true;  // FIRST: the pixel lies inside the scene's screen bounds (Frame::cx0..)
             if (FIRST) {
                 uint32_t s = fdiv(i, fr.div_pixels), p = i - s * fr.n_tile_pixels;
                 uint32_t ty, tx;
                 slot_pixel(fr, p, tx, ty);
-                PixelArgs a = pixel_args(fr.x0 + tx, fr.y0 + ty, fr.width, fr.height, fr.jitter[2 * s], fr.jitter[2 * s + 1], fr.aspect);
-                o = ld3(sc.cam.eye);
-                d = camera_dir(sc.cam, a.x, a.y);
+                const uint32_t gx = fr.x0 + tx, gy = fr.y0 + ty;
+                on_screen = gx >= fr.cx0 && gx < fr.cx1 && gy >= fr.cy0 && gy < fr.cy1;
+                if (on_screen) {
+                    PixelArgs a = pixel_args(gx, gy, fr.width, fr.height, fr.jitter[2 * s], fr.jitter[2 * s + 1], fr.aspect);
+                    o = ld3(sc.cam.eye);
+                    d = camera_dir(sc.cam, a.x, a.y);
+                }
             } else {
                 o = mk(in.o[0][i], in.o[1][i], in.o[2][i]);
                 d = mk(in.d[0][i], in.d[1][i], in.d[2][i]);
@@ -1492,8 +1505,10 @@ __global__ __launch_bounds__(PathBlock<DEPTH>::value) void k_path(Scene sc, Fram
             const PathRec rec = load_rec<FIRST>(in, i);  // in flight while the tree is walked
             double t = 1.7976931348623157e308;  // ray.rs:22 f64::MAX; t_min = 1e-5 (ray.rs:21)
             uint32_t nn = 0, nt = 0;
-            uint32_t leaf = (FIRST && sc.eye_nodes) ? traverse_eye<DEPTH, kPathBlock>(sc, d, 1e-5, t, stack + threadIdx.x)
-                                                    : traverse<DEPTH, false, false, kPathBlock>(sc, o, d, 1e-5, t, stack + threadIdx.x, nn, nt);
+            uint32_t leaf = PT_MISS;
+            if (on_screen)
+                leaf = (FIRST && sc.eye_nodes) ? traverse_eye<DEPTH, kPathBlock>(sc, d, 1e-5, t, stack + threadIdx.x)
+                                               : traverse<DEPTH, false, false, kPathBlock>(sc, o, d, 1e-5, t, stack + threadIdx.x, nn, nt);
             shade_vertex<FIRST, LAST, NEE, MATS, true>(sc, fr, bounce, in, i, rec, leaf, t, o, d, ls, r);
             if (NEE && !LAST && sc.fuse_shadow && r.shadow) {
                 // the light sample's visibility, in place: the shadow ray never leaves the registers

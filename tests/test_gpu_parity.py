@@ -466,3 +466,38 @@ def test_last_bounce_emitter_cull_is_bit_identical(gpu, monkeypatch, name):
     cfg = pt.Config(dim=48, samples_pr_pixel=2, bounces=2, seed=3, drop_nonfinite=True)
     img, ref = sl.render(cfg), ol.render(pt.Config(dim=48, samples_pr_pixel=2, bounces=2, seed=3, drop_nonfinite=True))
     assert (np.abs(img - ref) > 1e-6 * np.maximum(1.0, np.abs(ref))).mean() < 1e-2
+
+
+@pytest.mark.parametrize("name", ["CornellBox", "Test", "glossy_planes", "heightfield40"])
+def test_screen_bounds_cull_is_bit_identical(gpu, monkeypatch, name):
+    # primary rays through pixels outside the projection of the scene's root box are not generated:
+    # same image, whether the eye is outside the box (CornellBox: 44 % of the columns are culled),
+    # inside it, or the image is rendered in tiles / at odd sizes
+    if name == "heightfield40":
+        from pathtracer_amd.synthetic import heightfield_box
+        data = heightfield_box(cells=40)
+    else:
+        data = pt.scene_data(name)
+    monkeypatch.setenv("PT_SCREEN_CULL", "0")
+    full = pt.Scene(data, gpu)
+    monkeypatch.delenv("PT_SCREEN_CULL")
+    cull = pt.Scene(data, gpu)
+    for cfg in (pt.Config(width=320, height=180, samples_pr_pixel=3, bounces=2, seed=5, drop_nonfinite=True),
+                pt.Config(width=211, height=97, samples_pr_pixel=2, bounces=1, seed=2, nee=True, drop_nonfinite=True),
+                pt.Config(dim=64, samples_pr_pixel=2, bounces=0, seed=1)):
+        a = full.render(cfg)
+        assert a.tobytes() == cull.render(cfg).tobytes(), (name, cfg)
+        acc = np.zeros_like(a)
+        for x0, x1 in ((0, cfg.w // 3), (cfg.w // 3, cfg.w)):
+            cull.render(cfg, acc, tile=(x0, 0, x1, cfg.h))
+        assert acc.tobytes() == a.tobytes()
+    # a camera that sees the scene at the very edge of a wide image, and one looking away from it
+    import copy
+    for view in ((0.9, 0.1, -1.0), (0.0, 0.0, 1.0)):
+        moved = copy.copy(data)
+        c = data.camera
+        moved.camera = pt.Camera(c.eye, view, c.up_direction, c.camera_const)
+        a, b = pt.Scene(moved, gpu), O.OracleScene(moved)
+        cfg = pt.Config(width=160, height=48, samples_pr_pixel=2, bounces=1, seed=3, drop_nonfinite=True)
+        img, ref = a.render(cfg), b.render(cfg)
+        assert (np.abs(img - ref) > 1e-6 * np.maximum(1.0, np.abs(ref))).mean() < 1e-2
