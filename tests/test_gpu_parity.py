@@ -501,3 +501,19 @@ def test_screen_bounds_cull_is_bit_identical(gpu, monkeypatch, name):
         cfg = pt.Config(width=160, height=48, samples_pr_pixel=2, bounces=1, seed=3, drop_nonfinite=True)
         img, ref = a.render(cfg), b.render(cfg)
         assert (np.abs(img - ref) > 1e-6 * np.maximum(1.0, np.abs(ref))).mean() < 1e-2
+
+
+def test_thin_and_tiny_tiles_assemble_bitwise(scenes):
+    # tiles without a single whole 8x8 block (one pixel high, one pixel wide, 3x5, 9x7): the frame's
+    # slot order degenerates to its strips; the image assembled from them equals the one-call image
+    data, scene, oracle = scenes["CornellBox"]
+    cfg = pt.Config(width=37, height=23, samples_pr_pixel=3, bounces=2, seed=7, nee=True)
+    whole = scene.render(cfg)
+    for tw, th in ((37, 1), (1, 23), (3, 5), (9, 7), (16, 8)):
+        acc = np.zeros_like(whole)
+        for y0 in range(0, 23, th):
+            for x0 in range(0, 37, tw):
+                scene.render(cfg, acc, tile=(x0, y0, min(x0 + tw, 37), min(y0 + th, 23)))
+        assert acc.tobytes() == whole.tobytes(), (tw, th)
+    ref = oracle.render(cfg)
+    assert (np.abs(whole - ref) > 1e-9 * np.maximum(1.0, np.abs(ref))).mean() < 5e-3
