@@ -192,7 +192,7 @@ H3 hnorm(H3 a) {
 }
 H3 hneg(H3 a) { return {-a.x, -a.y, -a.z}; }
 
-// Traversal scheduling of a scene (pt_kernels.hip trace_range_vote / traverse).  Defaults from the
+// Traversal scheduling of a scene (pt_traverse.hip.h trace_range_vote / traverse).  Defaults from the
 // sweeps recorded in DESIGN.md "Traversal scheduling": primary rays one ray per lane; secondary and
 // shadow rays vote-scheduled over ranges of 256 rays when the tree is deeper than 8 levels (scenes
 // from ~500 triangles up).  Tuning runs and tests override it through the environment, read when
@@ -554,7 +554,7 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
     dv.lights = s->d_lights.as<ptd::Light>();
     dv.emissive = s->d_emissive.as<ptd::EmitTri>();
     dv.n_emissive = (uint32_t)emissive.size();
-    // last-bounce cull (pt_kernels.hip may_reach_emitter): needs a black background and emitters that
+    // last-bounce cull (pt_shade.hip.h may_reach_emitter): needs a black background and emitters that
     // are a few triangles; PT_LIGHT_CULL=0 switches it off (tests render both ways)
     dv.cull_last = !emissive_prim && emissive.size() <= ptd::kMaxCullEmitters && d->background[0] == 0. &&
                    d->background[1] == 0. && d->background[2] == 0.;

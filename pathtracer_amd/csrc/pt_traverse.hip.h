@@ -1,0 +1,599 @@
+// pt_traverse.hip.h — extend: the triangle test of triangle_mesh.rs:101-126, slab test, BVH traversal (one ray per lane, vote-scheduled ranges, eye-relative tables), k_extend, k_shadow
+// Part of the single translation unit pt_kernels.hip (device code is inlined across these files);
+// included from there, in order: pt_math.hip.h, pt_traverse.hip.h, pt_shade.hip.h.
+#pragma once
+#include "pt_device.h"
+
+#include "../../include/pt.h"
+
+namespace ptd {
+
+// ------------------------------------------------------------------------------------------------
+// triangle_mesh.rs:101-126.  The conditions are evaluated in a different order than the reference
+// (barycentrics before the distance, so most candidates cost one division instead of two); every
+// condition is computed with the reference's arithmetic and they have no side effects, so the
+// accept/reject decision and the accepted t are identical.
+struct TriV {
+    D3 v0, v1, v2;
+};
+__device__ __forceinline__ TriV widen(float4 a, float4 b, float4 c) {
+    return {mk((double)a.x, (double)a.y, (double)a.z), mk((double)b.x, (double)b.y, (double)b.z),
+            mk((double)c.x, (double)c.y, (double)c.z)};
+}
+__device__ __forceinline__ TriV load_tri(const Scene& sc, uint32_t leaf) {
+    const float4* tp = sc.tris + (size_t)leaf * 3;
+    return widen(tp[0], tp[1], tp[2]);
+}
+// the ray-direction-independent part of the test
+struct TriPre {
+    D3 e0, e1, normal, vo;
+    double num;
+};
+__device__ __forceinline__ TriPre tri_pre(const TriV& tr, D3 o) {
+    TriPre p;
+    p.e0 = tr.v1 - tr.v0;
+    p.e1 = tr.v0 - tr.v2;
+    p.normal = cross(p.e0, p.e1);
+    p.vo = tr.v0 - o;
+    p.num = dot(p.vo, p.normal);
+    return p;
+}
+__device__ __forceinline__ bool tri_test_core(const TriPre& p, D3 d, double t_min, double t_max, double& t_out,
+                                              double& v_out, double& w_out) {
+    double dn = dot(d, p.normal);
+    if (fabs(dn) < 1.0e-12) return false;
+    D3 tmp = cross(p.vo, d);
+    double a = dot(tmp, p.e1), b = dot(tmp, p.e0), num = p.num;
+    // Division-free exact rejects.  With |x| >= 2^-500 and 1e-12 <= |dn| <= 2^500 neither
+    // x * (1/dn) nor x / dn can round to zero, so their sign is sign(x) * sign(dn): the reference's
+    // `v < 0`, `w < 0` and (for t_min >= 0) `t < t_min` are decided without dividing.  NaNs and
+    // out-of-range magnitudes fail the guards and take the full path below.
+    if (fabs(dn) <= 0x1p500) {
+        bool dneg = dn < 0.;
+        if (fabs(a) >= 0x1p-500 && (a < 0.) != dneg) return false;                  // v < 0
+        if (fabs(b) >= 0x1p-500 && (b < 0.) != dneg) return false;                  // w < 0
+        if (t_min >= 0. && fabs(num) >= 0x1p-500 && (num < 0.) != dneg) return false;  // t < 0 <= t_min
+    }
+    double denom = 1. / dn;
+    double v = a * denom;
+    double w = b * denom;
+    if (v < 0.0 || w < 0.0 || v + w > 1.0) return false;
+    double t = num / dn;
+    if (t < t_min || t > t_max) return false;
+    t_out = t; v_out = v; w_out = w;
+    return true;
+}
+__device__ __forceinline__ bool tri_test(const TriV& tr, D3 o, D3 d, double t_min, double t_max, double& t_out,
+                                         double& v_out, double& w_out) {
+    return tri_test_core(tri_pre(tr, o), d, t_min, t_max, t_out, v_out, w_out);
+}
+
+// f64 slab test against an f32 box that the builder padded outward.  v_min/v_max_f64 return the
+// non-NaN operand, so a 0*inf (origin on a padded plane, parallel ray) yields a miss, which is
+// right: the padded plane holds no triangle of the box.
+__device__ __forceinline__ bool slab(double lox, double loy, double loz, double hix, double hiy, double hiz, D3 o,
+                                     D3 inv, double t_min, double t_max, double& t_near) {
+    double ax = (lox - o.x) * inv.x, bx = (hix - o.x) * inv.x;
+    double ay = (loy - o.y) * inv.y, by = (hiy - o.y) * inv.y;
+    double az = (loz - o.z) * inv.z, bz = (hiz - o.z) * inv.z;
+    double tn = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmax(fmin(az, bz), t_min));
+    double tf = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmin(fmax(az, bz), t_max));
+    t_near = tn;
+    return tn <= tf;
+}
+
+// BVH traversal, one ray per lane, stack in LDS laid out [entry][lane] (bank = lane: conflict-free).
+// ANY = stop at the first accepted triangle (shadow rays).  Returns leaf-order index / PT_MISS.
+// One node step: slab-test both children, pick the next node (near child first, far child pushed)
+// or pop.  kDone marks an empty stack; it is negative like a leaf reference but decodes to a
+// triangle offset >= 2^28, which no scene has.
+// geometry/mod.rs:31-72 Plane::intersect / Sphere::intersect, the accept/reject part
+__device__ __forceinline__ bool prim_test(const Prim& pr, D3 o, D3 d, double t_min, double t_max, double& t_out) {
+    if (pr.kind == PT_PRIM_PLANE) {
+        D3 n = ld3(pr.n);
+        double denom = dot(n, d);
+        if (fabs(denom) < 1e-6) return false;
+        double t = dot(ld3(pr.p) - o, n) / denom;
+        if (t > t_max || t < t_min) return false;
+        t_out = t;
+        return true;
+    }
+    D3 p = o - ld3(pr.p);
+    double b = dot(d, p);
+    double c = dot(p, p) - pr.radius * pr.radius;
+    double dd = sqrt(b * b - c);  // NaN when the ray misses: both comparisons below fail
+    double t1 = (-b - dd);
+    double t2 = (-b + dd);
+    if (t1 > t_min && t1 < t_max) { t_out = t1; return true; }
+    if (t2 > t_min && t2 < t_max) { t_out = t2; return true; }
+    return false;
+}
+// The analytic primitives are tested before the tree is walked: a hit shortens t_max for the
+// traversal, and with ids above every triangle id a triangle at a bit-identical t wins the tie.
+__device__ __forceinline__ void prims_closest(const Scene& sc, D3 o, D3 d, double t_min, double& t_max, uint32_t& best,
+                                              uint32_t& best_id) {
+    for (uint32_t k = 0; k < sc.n_prims; ++k) {
+        double t;
+        if (!prim_test(sc.prims[k], o, d, t_min, t_max, t)) continue;
+        if (best != PT_MISS && !(t < t_max)) continue;
+        best = best_id = PT_PRIM_BASE + k;
+        t_max = t;
+    }
+}
+#ifdef PT_DEBUG_TAIL
+__device__ unsigned long long g_dbg_tail[16384];
+extern "C" int pt_debug_tail(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_tail), sizeof(unsigned long long) * 16384);
+}
+#endif
+constexpr int kDone = (int)0x80000000;
+template <int DEPTH, bool STATS, int STRIDE = kTravBlock>
+__device__ __forceinline__ int node_step(const Scene& sc, int cur, D3 o, D3 inv, double t_min, double t_max, int* stk,
+                                         int& sp, uint32_t& n_nodes) {
+    const float4* np = sc.nodes + (size_t)cur * 4;
+    float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+    int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+    double tn0, tn1;
+    bool h0 = slab((double)n0.x, (double)n0.y, (double)n0.z, (double)n0.w, (double)n1.x, (double)n1.y, o, inv, t_min,
+                   t_max, tn0) && c0 != PT_BVH_EMPTY;
+    bool h1 = slab((double)n1.z, (double)n1.w, (double)n2.x, (double)n2.y, (double)n2.z, (double)n2.w, o, inv, t_min,
+                   t_max, tn1) && c1 != PT_BVH_EMPTY;
+    if (STATS) n_nodes += 2;
+    if (h0 && h1) {
+        int nearc = c0, farc = c1;
+        if (tn1 < tn0) { nearc = c1; farc = c0; }
+        if (sp < DEPTH) { stk[sp * STRIDE] = farc; ++sp; }
+        return nearc;
+    }
+    if (h0) return c0;
+    if (h1) return c1;
+    if (sp == 0) return kDone;
+    --sp;
+    return stk[sp * STRIDE];
+}
+
+// BVH traversal of the rays [begin, end) by one wave, stack in LDS laid out [entry][lane]
+// (bank = lane: conflict-free).  ANY = stop at the first accepted triangle (shadow rays).
+//
+// Every lane is a small state machine whose next unit of work is one of
+//   node   (cur >= 0)             slab-test the two children of an inner node, descend / push / pop
+//   tri    (cur < 0, != kDone)    test ONE triangle of the leaf range encoded in cur, advance / pop
+//   retire (cur == kDone)         hand the finished ray to done() and claim the next unclaimed ray
+//                                 of the wave's range (ballot + mbcnt rank: no atomics, no memory)
+// and each trip of the loop the wave runs only the kind most of its lanes are waiting for (a
+// ballot vote).  The chosen body therefore runs with at least a third — typically well over half —
+// of the working lanes active, whatever mix of cheap and expensive rays the wave holds.  The
+// one-ray-per-lane while-while form measured 16 % lane utilisation on incoherent secondary rays
+// of the 10M-triangle scene: every lane waited for the longest descent, the largest leaf and the
+// longest ray of its 64.
+// fetch(idx, o, d, t_min, t_max) loads ray idx; done(idx, leaf_tri, t) consumes its result.
+// Where a persistent wave gets its next range of queue entries from: the per-segment work cursors
+// of a segmented queue.  A wave starts on segment (wave id mod kSegs) and moves on round-robin when
+// a segment is used up; one atomic per claimed range, executed by one lane.  With cursors == nullptr
+// the wave owns exactly the range it was started with.
+struct RangePool {
+    uint32_t* cursors;
+    const uint32_t* counts;
+    uint32_t seg_size, grab, seg, tried;
+    __device__ __forceinline__ bool next(uint32_t& begin, uint32_t& end) {
+        if (!cursors) return false;
+        const uint32_t lane = threadIdx.x & 63u;
+        static_assert(kSegs == 64, "one lane looks at one segment");
+        // `tried` bounds the retries: a claim can lose a race, but every lost race means another wave
+        // took a range, and once a segment is seen empty it stays empty
+        while (tried < 4 * kSegs) {
+            // one coherent load per lane: which segments still have unclaimed entries?
+            const uint32_t live_k = min(counts[lane * kCtrStride], seg_size);
+            const uint32_t cur_k = __hip_atomic_load(&cursors[lane * kCtrStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long open = __ballot(cur_k < live_k);
+            if (!open) return false;
+            // first open segment at or after `seg`, cyclically
+            const unsigned long long rot = seg ? ((open >> seg) | (open << (64u - seg))) : open;
+            seg = (seg + (uint32_t)__builtin_ctzll(rot)) % kSegs;
+            const uint32_t live = (uint32_t)__builtin_amdgcn_readlane((int)live_k, (int)seg);
+            // guided schedule: full ranges while the segment is well stocked, smaller ones towards
+            // its end, so that the waves of a launch run dry at about the same time
+            const uint32_t rem = live - (uint32_t)__builtin_amdgcn_readlane((int)cur_k, (int)seg);
+            const uint32_t g = rem >= 32u * grab ? grab : (rem >= 8u * grab ? max(64u, grab / 2u) : 64u);
+            uint32_t c = 0;
+            if (lane == 0) c = atomicAdd(&cursors[seg * kCtrStride], g);
+            c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+            if (c < live) {
+                begin = seg * seg_size + c;
+                end = seg * seg_size + min(c + g, live);
+                return true;
+            }
+            ++tried;
+        }
+        return false;
+    }
+};
+
+template <int DEPTH, bool ANY, bool STATS, class Fetch, class Done>
+__device__ __forceinline__ void trace_range_vote(const Scene& sc, uint32_t begin, uint32_t end, RangePool pool, int* stk,
+                                                 Fetch fetch, Done done, uint32_t& n_nodes, uint32_t& n_tris) {
+    uint32_t cursor = begin;  // wave-uniform: first unclaimed ray
+    bool more = pool.cursors != nullptr;  // wave-uniform: the pool may hold further ranges
+    bool busy = false;
+    uint32_t idx = 0, best = PT_MISS, best_id = PT_MISS;
+    D3 o = mk(0., 0., 0.), d = o, inv = o;
+    double t_min = 0., t_max = 0.;
+    int sp = 0, cur = kDone;
+    for (;;) {
+        if (more && cursor >= end) {  // the range is handed out: claim the next one (lanes still at work keep going)
+            more = pool.next(begin, end);
+            if (more) cursor = begin;
+        }
+        const bool is_node = cur >= 0, is_ret = cur == kDone && (busy || cursor < end);
+        const bool is_tri = cur < 0 && cur != kDone;
+        const unsigned long long m_ret = __ballot(is_ret);
+        const int n_node = __popcll(__ballot(is_node)), n_tri = __popcll(__ballot(is_tri)), n_ret = __popcll(m_ret);
+        if (n_node >= n_tri && n_node >= n_ret) {
+            if (n_node == 0) break;  // nothing left in the range
+            if (is_node) cur = node_step<DEPTH, STATS>(sc, cur, o, inv, t_min, t_max, stk, sp, n_nodes);
+        } else if (n_tri >= n_ret) {
+            if (is_tri) {
+                uint32_t code = (uint32_t)~cur, first = code >> 3, cnt = (code & 7u) + 1u;
+                bool stop = false;
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const float4* tp = sc.tris + (size_t)(first + k) * 3;
+                    float4 a = tp[0], b = tp[1], c = tp[2];
+                    TriV tr = widen(a, b, c);
+                    if (STATS) n_tris += 1;
+                    double t, v, w;
+                    if (!tri_test(tr, o, d, t_min, t_max, t, v, w)) continue;
+                    uint32_t gid = (uint32_t)__float_as_int(a.w);
+                    // the reference accepts t == t_max (triangle_mesh.rs:113) and keeps the candidate
+                    // tested last; the build-defined rule keeps the lowest triangle id
+                    if (best != PT_MISS && !(t < t_max || gid < best_id)) continue;
+                    best = first + k; best_id = gid; t_max = t;
+                    if (ANY) { stop = true; break; }
+                }
+                if (stop || sp == 0) cur = kDone;
+                else { --sp; cur = stk[sp * kTravBlock]; }
+            }
+        } else {
+            if (is_ret) {
+                if (busy) done(idx, best, t_max);
+                busy = false;
+                uint32_t cand = cursor + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_ret >> 32),
+                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)m_ret, 0u));
+                if (cand < end) {
+                    idx = cand;
+                    fetch(idx, o, d, t_min, t_max);
+                    inv = mk(1. / d.x, 1. / d.y, 1. / d.z);
+                    best = PT_MISS; best_id = PT_MISS;
+                    sp = 0;
+                    cur = sc.n_nodes ? 0 : kDone;
+                    if (sc.n_prims) {
+                        prims_closest(sc, o, d, t_min, t_max, best, best_id);
+                        if (ANY && best != PT_MISS) cur = kDone;
+                    }
+                    busy = true;
+                }
+            }
+            if (cursor < end) cursor += (uint32_t)n_ret;
+        }
+    }
+}
+
+// The other scheduling of the same work, one ray per lane for its whole life: "while-while" —
+// the wave keeps stepping through inner nodes until every lane holds a leaf (or is done), then all
+// of them test their leaf together.  No bookkeeping per unit of work, so it wins where the rays of
+// a wave are coherent or every ray is short (primary rays: 96 % lane utilisation on CornellBox;
+// scenes under ~500 triangles), and loses by 15-40 % on incoherent rays in deeper trees (measured
+// crossover: DESIGN.md "Traversal scheduling").  Returns leaf-order index / PT_MISS.
+template <int DEPTH, bool ANY, bool STATS, int STRIDE = kTravBlock>
+__device__ __forceinline__ uint32_t traverse(const Scene& sc, D3 o, D3 d, double t_min, double& t_max, int* stk,
+                                             uint32_t& n_nodes, uint32_t& n_tris) {
+    uint32_t best = PT_MISS, best_id = PT_MISS;
+    if (sc.n_prims) {
+        prims_closest(sc, o, d, t_min, t_max, best, best_id);
+        if (ANY && best != PT_MISS) return best;
+    }
+    if (sc.n_nodes == 0) return best;
+    D3 inv = mk(1. / d.x, 1. / d.y, 1. / d.z);
+    int sp = 0;
+    int cur = 0;
+    while (cur != kDone) {
+        while (cur >= 0) cur = node_step<DEPTH, STATS, STRIDE>(sc, cur, o, inv, t_min, t_max, stk, sp, n_nodes);
+        if (cur == kDone) break;
+        int code = ~cur;
+        uint32_t first = (uint32_t)code >> 3, cnt = ((uint32_t)code & 7u) + 1u;
+        for (uint32_t k = 0; k < cnt; ++k) {
+            const float4* tp = sc.tris + (size_t)(first + k) * 3;
+            float4 a = tp[0], b = tp[1], c = tp[2];
+            TriV tr = widen(a, b, c);
+            if (STATS) n_tris += 1;
+            double t, v, w;
+            if (!tri_test(tr, o, d, t_min, t_max, t, v, w)) continue;
+            uint32_t gid = (uint32_t)__float_as_int(a.w);
+            // the reference accepts t == t_max (triangle_mesh.rs:113) and keeps the candidate
+            // tested last; the build-defined rule keeps the lowest triangle id
+            if (best != PT_MISS && !(t < t_max || gid < best_id)) continue;
+            best = first + k; best_id = gid; t_max = t;
+            if (ANY) return best;
+        }
+        if (sp == 0) break;
+        --sp;
+        cur = stk[sp * STRIDE];
+    }
+    return best;
+}
+
+// ---- primary rays of a small scene: the eye-relative tables (pt_device.h EyeNode / EyeTri) -----
+__device__ __forceinline__ bool slab_rel(const double* r, D3 inv, double t_min, double t_max, double& t_near) {
+    double ax = r[0] * inv.x, bx = r[3] * inv.x;   // r = (lo - o, hi - o): the subtraction of slab() is in the table
+    double ay = r[1] * inv.y, by = r[4] * inv.y;
+    double az = r[2] * inv.z, bz = r[5] * inv.z;
+    double tn = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmax(fmin(az, bz), t_min));
+    double tf = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmin(fmax(az, bz), t_max));
+    t_near = tn;
+    return tn <= tf;
+}
+__global__ void k_build_eye_tables(Scene sc, EyeNode* nodes, EyeTri* tris) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const D3 o = ld3(sc.cam.eye);
+    if (i < sc.n_nodes) {
+        const float4* np = sc.nodes + (size_t)i * 4;
+        float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+        const float b[12] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w};
+        const double oo[3] = {o.x, o.y, o.z};
+        for (int k = 0; k < 12; ++k) nodes[i].rel[k] = (double)b[k] - oo[k % 3];
+        nodes[i].child[0] = __float_as_int(n3.x);
+        nodes[i].child[1] = __float_as_int(n3.y);
+        nodes[i].pad[0] = nodes[i].pad[1] = 0;
+    }
+    if (i < sc.n_tris) {
+        TriPre p = tri_pre(load_tri(sc, i), o);
+        EyeTri& e = tris[i];
+        e.e0[0] = p.e0.x; e.e0[1] = p.e0.y; e.e0[2] = p.e0.z;
+        e.e1[0] = p.e1.x; e.e1[1] = p.e1.y; e.e1[2] = p.e1.z;
+        e.normal[0] = p.normal.x; e.normal[1] = p.normal.y; e.normal[2] = p.normal.z;
+        e.vo[0] = p.vo.x; e.vo[1] = p.vo.y; e.vo[2] = p.vo.z;
+        e.num = p.num;
+        e.gid = (uint32_t)__float_as_int(sc.tris[(size_t)i * 3].w);
+        e.pad = 0;
+    }
+}
+// traverse() for a ray that starts at the eye (closest hit only)
+template <int DEPTH, int STRIDE>
+__device__ __forceinline__ uint32_t traverse_eye(const Scene& sc, D3 d, double t_min, double& t_max, int* stk) {
+    uint32_t best = PT_MISS, best_id = PT_MISS;
+    if (sc.n_prims) prims_closest(sc, ld3(sc.cam.eye), d, t_min, t_max, best, best_id);
+    if (sc.n_nodes == 0) return best;
+    D3 inv = mk(1. / d.x, 1. / d.y, 1. / d.z);
+    int sp = 0;
+    int cur = 0;
+    while (cur != kDone) {
+        while (cur >= 0) {
+            const EyeNode& n = sc.eye_nodes[cur];
+            int c0 = n.child[0], c1 = n.child[1];
+            double tn0, tn1;
+            bool h0 = slab_rel(n.rel, inv, t_min, t_max, tn0) && c0 != PT_BVH_EMPTY;
+            bool h1 = slab_rel(n.rel + 6, inv, t_min, t_max, tn1) && c1 != PT_BVH_EMPTY;
+            if (h0 && h1) {
+                int nearc = c0, farc = c1;
+                if (tn1 < tn0) { nearc = c1; farc = c0; }
+                if (sp < DEPTH) { stk[sp * STRIDE] = farc; ++sp; }
+                cur = nearc;
+            } else if (h0) cur = c0;
+            else if (h1) cur = c1;
+            else if (sp == 0) cur = kDone;
+            else { --sp; cur = stk[sp * STRIDE]; }
+        }
+        if (cur == kDone) break;
+        int code = ~cur;
+        uint32_t first = (uint32_t)code >> 3, cnt = ((uint32_t)code & 7u) + 1u;
+        for (uint32_t k = 0; k < cnt; ++k) {
+            const EyeTri& e = sc.eye_tris[first + k];
+            TriPre p{ld3(e.e0), ld3(e.e1), ld3(e.normal), ld3(e.vo), e.num};
+            double t, v, w;
+            if (!tri_test_core(p, d, t_min, t_max, t, v, w)) continue;
+            uint32_t gid = e.gid;
+            if (best != PT_MISS && !(t < t_max || gid < best_id)) continue;  // lowest id wins a tie, as in traverse()
+            best = first + k; best_id = gid; t_max = t;
+        }
+        if (sp == 0) break;
+        --sp;
+        cur = stk[sp * STRIDE];
+    }
+    return best;
+}
+
+// Exclusive end of the live entries in the segment that holds entry i0 (i0 = first entry of a
+// workgroup; a workgroup never straddles segments).  Dense queues have one segment [0, n).
+__device__ __forceinline__ uint32_t live_end(const Live& lv, uint32_t i0) {
+    if (!lv.counts) return lv.n;
+    uint32_t seg = i0 / lv.seg_size;
+    return seg * lv.seg_size + min(lv.counts[seg * kCtrStride], lv.seg_size);
+}
+// Logical block `blk` (of BLOCK entries) of a sparsely filled segmented queue -> its entry range;
+// false past the last live block.  Every wave works it out for itself: lane k takes segment k's
+// count (kSegs == 64), a wave prefix sum gives the first block of each segment, a ballot the segment.
+template <int BLOCK>
+__device__ __forceinline__ bool sparse_block(const Live& lv, uint32_t blk, uint32_t& begin, uint32_t& end) {
+    static_assert(kSegs == 64, "one segment per lane");
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t cnt = min(lv.counts[lane * kCtrStride], lv.seg_size);
+    const uint32_t nb = (cnt + BLOCK - 1) / BLOCK;
+    uint32_t pre = nb;  // inclusive prefix
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t v = __shfl_up(pre, d);
+        if (lane >= (uint32_t)d) pre += v;
+    }
+    const unsigned long long m = __ballot(pre > blk);
+    if (!m) return false;
+    const int seg = __ffsll((long long)m) - 1;
+    const uint32_t first = __shfl(pre - nb, seg), seg_cnt = __shfl(cnt, seg);
+    begin = seg * lv.seg_size + (blk - first) * BLOCK;
+    end = min(begin + BLOCK, seg * lv.seg_size + seg_cnt);
+    return true;
+}
+__device__ __forceinline__ unsigned long long live_total(const Live& lv) {
+    if (!lv.counts) return lv.n;
+    unsigned long long t = 0;
+    for (uint32_t k = 0; k < kSegs; ++k) t += min(lv.counts[k * kCtrStride], lv.seg_size);
+    return t;
+}
+
+// XCD-aware block remap.  Hardware deals consecutive workgroups round-robin over the 8 XCDs, so
+// blocks b and b+8 share an L2.  Work is handed out in chunks of kChunk consecutive blocks
+// (kChunk * 64 rays = a few image rows of primary rays): XCD x processes chunks x, x+8, x+16, ...
+// Consecutive rays stay on one L2 (locality for node/triangle fetches) while every XCD sees the
+// same mix of cheap and expensive regions (a contiguous eighth per XCD left XCDs idle: the ceiling
+// band finishes long before the heightfield band).  Bijective on [0, nb) when nb % (8*kChunk) == 0.
+constexpr uint32_t kChunkRays = 4096;  // wave_rays divides it
+__device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t chunk) {
+    uint32_t x = b & 7u, k = b >> 3;
+    return ((k / chunk) * 8u + x) * chunk + (k % chunk);
+}
+__host__ __device__ __forceinline__ uint32_t trav_blocks(uint32_t n, uint32_t wave_rays) {  // blocks for n rays, padded to whole chunk rounds
+    uint32_t nb = (n + wave_rays - 1) / wave_rays, r = 8u * (kChunkRays / wave_rays);
+    return (nb + r - 1) / r * r;
+}
+
+// PRIMARY: the generate stage (main.rs:412-427 + scene.rs:37-45) runs in the fetch — ray i is path
+// slot i of the batch and its camera ray is built in registers; nothing is read from the queue.
+// One wave per workgroup; workgroup b owns the wave_rays queue entries [b, b+1) * wave_rays.
+template <int DEPTH, bool STATS, bool PRIMARY, bool VOTE>
+__global__ __launch_bounds__(kTravBlock) void k_extend(Scene sc, Frame fr, Queue q, const double* __restrict__ tmin,
+                                                   const double* __restrict__ tmax, Live live, uint32_t wave_rays,
+                                                   Hits hits, Counters* ctr) {
+    __shared__ int stack[DEPTH * kTravBlock];
+    if (ctr && blockIdx.x == 0 && threadIdx.x == 0)
+        atomicAdd(&ctr->rays, PRIMARY ? (unsigned long long)fr.n_on_screen * fr.n_samples : live_total(live));
+    // wave w of the launch owns the wave_rays queue entries [w, w + 1) * wave_rays
+    const uint32_t wib = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t block_rays = wave_rays * (kTravBlock / 64);
+    uint32_t begin, end;
+    RangePool pool{nullptr, nullptr, 0, 0, 0, 0};
+    if (VOTE && live.cursors) {
+        // persistent waves: ranges of wave_rays entries are claimed from the segments' work cursors
+        pool = RangePool{live.cursors, live.counts, live.seg_size, wave_rays,
+                         (blockIdx.x * (kTravBlock / 64) + wib) % kSegs, 0};
+        if (!pool.next(begin, end)) return;
+    } else if (live.counts) {
+        // segmented queue: live entries are already spread evenly over the index range, and the
+        // hardware's round-robin block placement spreads them over the XCDs
+        begin = blockIdx.x * block_rays + wib * wave_rays;
+        if (begin >= live.n) return;
+        end = min(begin + wave_rays, live_end(live, begin));
+    } else {
+        // dense queue [0, n): only the first trav_blocks(n) blocks take part, remapped in chunks
+        if (blockIdx.x >= trav_blocks(live.n, block_rays)) return;
+        begin = xcd_block(blockIdx.x, kChunkRays / block_rays) * block_rays + wib * wave_rays;
+        end = min(begin + wave_rays, live.n);
+    }
+    if (begin >= end) return;
+    uint32_t nn = 0, nt = 0;
+    auto fetch = [&](uint32_t i, D3& o, D3& d, double& t_min, double& t_max) {
+            if (PRIMARY) {
+                uint32_t s = fdiv(i, fr.div_pixels), p = i - s * fr.n_tile_pixels;
+                uint32_t ty, tx;
+                slot_pixel(fr, p, tx, ty);
+                const uint32_t gx = fr.x0 + tx, gy = fr.y0 + ty;
+                PixelArgs a = pixel_args(gx, gy, fr.width, fr.height, fr.jitter[2 * s], fr.jitter[2 * s + 1], fr.aspect);
+                o = ld3(sc.cam.eye);
+                d = camera_dir(sc.cam, a.x, a.y);
+                t_min = 1e-5;
+                // outside the scene's screen bounds (Frame::cx0..): an empty t range, nothing can be hit
+                t_max = (gx >= fr.cx0 && gx < fr.cx1 && gy >= fr.cy0 && gy < fr.cy1) ? 1.7976931348623157e308 : -1.;
+                return;
+            } else {
+                o = mk(q.o[0][i], q.o[1][i], q.o[2][i]);
+                d = mk(q.d[0][i], q.d[1][i], q.d[2][i]);
+            }
+            t_min = tmin ? tmin[i] : 1e-5;                    // ray.rs:21
+            t_max = tmax ? tmax[i] : 1.7976931348623157e308;  // ray.rs:22 f64::MAX
+        };
+    auto done = [&](uint32_t i, uint32_t tri, double t) {
+            hits.tri[i] = tri;
+            hits.t[i] = t;
+        };
+    if (VOTE) {
+#ifdef PT_DEBUG_TAIL
+        unsigned long long dbg_t0 = wall_clock64();
+#endif
+        trace_range_vote<DEPTH, false, STATS>(sc, begin, end, pool, stack + threadIdx.x, fetch, done, nn, nt);
+#ifdef PT_DEBUG_TAIL
+        if (!STATS && live.cursors && lane == 0 && blockIdx.x < 8192) { g_dbg_tail[2 * blockIdx.x] = dbg_t0; g_dbg_tail[2 * blockIdx.x + 1] = wall_clock64(); }
+#endif
+    } else if (begin + lane < end) {  // wave_rays == 64
+        uint32_t i = begin + lane;
+        D3 o, d;
+        double t_min, t_max;
+        fetch(i, o, d, t_min, t_max);
+        if (PRIMARY && t_max < 0.) done(i, PT_MISS, t_max);  // off screen
+        else done(i, traverse<DEPTH, false, STATS>(sc, o, d, t_min, t_max, stack + threadIdx.x, nn, nt), t_max);
+    }
+    if (STATS) {
+        // wave-level reduction, one atomic pair per wave
+        for (int off = 32; off > 0; off >>= 1) {
+            nn += __shfl_down(nn, off);
+            nt += __shfl_down(nt, off);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&ctr->nodes, (unsigned long long)nn);
+            atomicAdd(&ctr->tris, (unsigned long long)nt);
+        }
+    }
+}
+
+// color_result += add for a slot that may not hold a value yet (Sample3).  One lane per slot and
+// launch, so only this lane can set the slot's bit; other bits of the word change under it.
+__device__ __forceinline__ void radiance_add(const Sample3& ls, uint32_t slot, D3 add) {
+    const unsigned long long bit = 1ull << (slot & 63u);
+    double* c = ls.c + (size_t)slot * 3;
+    if (ls.lit[slot >> 6] & bit) {
+        c[0] += add.x; c[1] += add.y; c[2] += add.z;
+    } else {
+        c[0] = 0. + add.x; c[1] = 0. + add.y; c[2] = 0. + add.z;
+        atomicOr(ls.lit + (slot >> 6), bit);
+    }
+}
+
+template <int DEPTH, bool VOTE>
+__global__ __launch_bounds__(kTravBlock) void k_shadow(Scene sc, ShadowQueue sq, Live live, uint32_t wave_rays, Sample3 ls,
+                                                   Counters* ctr) {
+    __shared__ int stack[DEPTH * kTravBlock];
+    if (ctr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->shadow_rays, live_total(live));
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t begin, end;
+    RangePool pool{nullptr, nullptr, 0, 0, 0, 0};
+    if (VOTE && live.cursors) {
+        pool = RangePool{live.cursors, live.counts, live.seg_size, wave_rays,
+                         (blockIdx.x * (kTravBlock / 64) + (threadIdx.x >> 6)) % kSegs, 0};
+        if (!pool.next(begin, end)) return;
+    } else {
+        begin = (blockIdx.x * (kTravBlock / 64) + (threadIdx.x >> 6)) * wave_rays;
+        if (begin >= live.n) return;
+        end = min(begin + wave_rays, live_end(live, begin));
+    }
+    if (begin >= end) return;
+    uint32_t nn = 0, nt = 0;
+    auto fetch = [&](uint32_t i, D3& o, D3& d, double& t_min, double& t_max) {
+            o = mk(sq.o[0][i], sq.o[1][i], sq.o[2][i]);
+            d = mk(sq.d[0][i], sq.d[1][i], sq.d[2][i]);
+            t_min = 1e-5;
+            t_max = sq.tmax[i];
+        };
+    auto done = [&](uint32_t i, uint32_t tri, double) {
+            if (tri != PT_MISS) return;
+            // unoccluded: the light sample counts (one shadow ray per path slot and launch)
+            radiance_add(ls, sq.slot[i], mk(sq.c[0][i], sq.c[1][i], sq.c[2][i]));
+        };
+    if (VOTE) {
+        trace_range_vote<DEPTH, true, false>(sc, begin, end, pool, stack + threadIdx.x, fetch, done, nn, nt);
+    } else if (begin + lane < end) {  // wave_rays == 64
+        uint32_t i = begin + lane;
+        D3 o, d;
+        double t_min, t_max;
+        fetch(i, o, d, t_min, t_max);
+        done(i, traverse<DEPTH, true, false>(sc, o, d, t_min, t_max, stack + threadIdx.x, nn, nt), t_max);
+    }
+}
+
+
+}  // namespace ptd
