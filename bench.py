@@ -271,6 +271,7 @@ def main():
                                    f"bounces={args.bounces}{', NEE' if args.nee else ''}{', textures' if args.textures else ''}, {args.spp} spp per step per GPU"
                                    + (" (BASELINE.json configs[1])" if args.scene == "CornellBox" else ""),
                        "triangles": data.n_tris,
+                       "exact_culls": {k: os.environ.get(k, "1") != "0" for k in ("PT_SCREEN_CULL", "PT_LIGHT_CULL")},
                        "partitioning": "sample ranges + one RCCL reduce" if world > 1 else "single GPU",
                        "samples_per_step": npix * args.spp * world},
             "mrays_per_s": round(total_rays / dt / 1e6, 3),
