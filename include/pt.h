@@ -189,7 +189,9 @@ enum { PT_K_GENERATE = 0, PT_K_EXTEND, PT_K_SHADE, PT_K_SHADOW, PT_K_ACCUMULATE,
 
 typedef struct pt_stats {
     uint64_t samples;        /* render() calls (main.rs:283) */
-    uint64_t rays;           /* trace_closest calls (scene.rs:61) */
+    uint64_t rays;           /* trace_closest calls (scene.rs:61) actually made: rays that provably add
+                              * nothing (outside the scene's screen bounds; last-bounce rays that miss every
+                              * emitter) are neither traced nor counted */
     uint64_t shadow_rays;    /* trace_any calls (scene.rs:66) */
     uint64_t nodes_visited;  /* child boxes slab-tested (32 B each); only with pt_set_profiling(..,2) */
     uint64_t tris_tested;    /* Triangle::intersect calls (triangle_mesh.rs:101) */
