@@ -9,8 +9,10 @@ bounces = 2, f64.  A "step" is one wavefront pass of the hot path over `--spp` f
 image (generate -> [extend -> shade] x 3 -> accumulate).  With N > 1 the work is split by
 sample ranges: every rank renders the full image for its own, disjoint frame indices (fixed
 per-GPU work => weak scaling) and the f64 accumulation buffers are summed onto rank 0 with one
-RCCL reduce at the end of the timed region (partitioning 2).  The scene and the
-accumulation buffer are resident in HBM before the timed region starts.
+RCCL reduce at the end of the timed region (partitioning 2).  `--partition tiles` is
+the other form (§8e partitioning 1): row bands of the one image, every rank the same frames, one
+RCCL all-gather at the end (fixed total work => strong scaling).  The scene and the accumulation
+buffer are resident in HBM before the timed region starts.
 
 Prints ONE JSON line on rank 0; see DESIGN.md "Measurement" for the roofline/cpu_baseline fields.
 """
@@ -37,6 +39,10 @@ def main():
     ap.add_argument("--scene", default="CornellBox", help="models/<scene>.obj, or 'heightfield' (SURVEY config 5)")
     ap.add_argument("--cells", type=int, default=2236, help="heightfield resolution (2236 -> 9,999,392 triangles)")
     ap.add_argument("--bounces", type=int, default=2)
+    ap.add_argument("--partition", choices=("samples", "tiles"), default="samples",
+                    help="N > 1: 'samples' = every rank renders the whole image for its own frames, one RCCL reduce "
+                         "(weak scaling, the measured default); 'tiles' = row bands of the one image, one RCCL "
+                         "all-gather (SURVEY.md §8e partitioning 1, strong scaling)")
     ap.add_argument("--nee", action="store_true", help="next-event estimation (shadow rays) on")
     ap.add_argument("--textures", action="store_true", help="load map_Kd textures (BASELINE configs[3]: --scene Test)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
@@ -79,10 +85,34 @@ def main():
     stream = torch.cuda.current_stream(dev).cuda_stream
     npix = args.width * args.height
 
+    tiles = world > 1 and args.partition == "tiles"
+    if tiles and args.height % world:
+        raise SystemExit(f"--partition tiles needs --height divisible by the number of ranks ({args.height} % {world})")
+    band = args.height // world if tiles else args.height
+    y0 = rank * band if tiles else 0
+
     def step(i):
-        # frames [base, base + spp): disjoint across ranks and steps
-        base = (i * world + rank) * args.spp
-        scene.render_device(cfg, accum.data_ptr(), base, args.spp, stream=stream)
+        if tiles:   # every rank the same frames, its own rows
+            scene.render_device(cfg, accum.data_ptr(), i * args.spp, args.spp, tile=(0, y0, args.width, y0 + band),
+                                stream=stream)
+        else:       # frames [base, base + spp): disjoint across ranks and steps
+            scene.render_device(cfg, accum.data_ptr(), (i * world + rank) * args.spp, args.spp, stream=stream)
+
+    def exchange():   # the job's one exchange, RCCL over xGMI (gloo through the host in rehearsals)
+        if tiles:
+            mine = accum[y0:y0 + band].contiguous()
+            if backend == "nccl":
+                dist.all_gather_into_tensor(accum.view(-1), mine.view(-1))
+            else:
+                parts = [torch.empty(mine.shape, dtype=mine.dtype) for _ in range(world)]
+                dist.all_gather(parts, mine.cpu())
+                accum.copy_(torch.cat(parts, dim=0))
+        elif backend == "nccl":
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        else:
+            host = accum.cpu()
+            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+            accum.copy_(host)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -94,7 +124,10 @@ def main():
         step(i)
     if world > 1 and backend == "nccl":
         # first use of a collective builds channels and loads its kernel: not part of a step
-        dist.reduce(torch.zeros_like(accum), dst=0, op=dist.ReduceOp.SUM)
+        if tiles:
+            dist.all_gather_into_tensor(torch.zeros_like(accum).view(-1), torch.zeros_like(accum[y0:y0 + band]).view(-1))
+        else:
+            dist.reduce(torch.zeros_like(accum), dst=0, op=dist.ReduceOp.SUM)
     fence()
     scene.reset_stats()
     scene.set_profiling(1)  # HIP events around every kernel launch of the timed region
@@ -103,12 +136,7 @@ def main():
     for i in range(args.steps):
         step(args.warmup + i)
     if world > 1:
-        if backend == "nccl":
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI: the job's one exchange
-        else:
-            host = accum.cpu()
-            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
-            accum.copy_(host)
+        exchange()
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -118,7 +146,7 @@ def main():
     st = scene.stats()
     scene.set_profiling(0)
 
-    samples_per_rank = npix * args.spp * args.steps
+    samples_per_rank = (band * args.width) * args.spp * args.steps
     rays_t = torch.tensor([float(st["rays"])], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(rays_t, op=dist.ReduceOp.SUM)
@@ -264,7 +292,7 @@ def main():
         out = {
             "metric": "Msamples/s", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": n_gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": "strong" if tiles else "weak", "vs_baseline": None, "dtype": "f64",
             "data": (f"synthetic heightfield box, {data.n_tris} triangles, seed 12345" if args.scene == "heightfield"
                      else f"reference scene models/{args.scene}.obj") + ", counter-based RNG (no dataset)",
             "config": {"workload": f"{args.scene}{'' if args.scene == 'heightfield' else '.obj'} {args.width}x{args.height} "
@@ -272,8 +300,8 @@ def main():
                                    + (" (BASELINE.json configs[1])" if args.scene == "CornellBox" else ""),
                        "triangles": data.n_tris,
                        "exact_culls": {k: os.environ.get(k, "1") != "0" for k in ("PT_SCREEN_CULL", "PT_LIGHT_CULL")},
-                       "partitioning": "sample ranges + one RCCL reduce" if world > 1 else "single GPU",
-                       "samples_per_step": npix * args.spp * world},
+                       "partitioning": ("row-band tiles + one RCCL all-gather" if tiles else "sample ranges + one RCCL reduce") if world > 1 else "single GPU",
+                       "samples_per_step": band * args.width * args.spp * world},
             "mrays_per_s": round(total_rays / dt / 1e6, 3),
             "roofline": roofline,
             "cpu_baseline": cpu,
