@@ -72,7 +72,7 @@ struct PixelArgs {
     double x, y, ddx, ddy;
 };
 __device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) { return (uint32_t)(((unsigned long long)n * f.mul) >> f.shift); }
-// slot within a frame <-> pixel of the tile (Frame: 8x8 blocks, right strip, bottom rows)
+// slot within a frame -> pixel of the tile (Frame: 8x8 blocks, right strip, bottom rows)
 __device__ __forceinline__ void slot_pixel(const Frame& fr, uint32_t p, uint32_t& tx, uint32_t& ty) {
     if (p < fr.n8) {
         uint32_t b = p >> 6, w = p & 63u;
@@ -92,11 +92,6 @@ __device__ __forceinline__ void slot_pixel(const Frame& fr, uint32_t p, uint32_t
         tx = q - yy * fr.tile_w;
         ty = fr.h8 + yy;
     }
-}
-__device__ __forceinline__ uint32_t pixel_slot(const Frame& fr, uint32_t tx, uint32_t ty) {
-    if (tx < fr.w8 && ty < fr.h8) return (((ty >> 3) * fr.bw + (tx >> 3)) << 6) + ((ty & 7u) << 3) + (tx & 7u);
-    if (ty < fr.h8) return fr.n8 + ty * fr.rw + (tx - fr.w8);
-    return fr.n8 + fr.rw * fr.h8 + (ty - fr.h8) * fr.tile_w + tx;
 }
 __device__ __forceinline__ PixelArgs pixel_args(uint32_t px, uint32_t py, uint32_t w, uint32_t h, double dx, double dy,
                                                 double aspect /* (double)w / (double)h: 1.0 for the reference's square images (F7) */) {

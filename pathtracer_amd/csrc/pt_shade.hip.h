@@ -845,14 +845,16 @@ __global__ __launch_bounds__(PathBlock<DEPTH>::value) void k_path(Scene sc, Fram
 // accumulate: main.rs:434-436, frames of the batch added in index order (deterministic f64 sum)
 __global__ __launch_bounds__(kBlock) void k_accumulate(Frame fr, Sample3 ls, const unsigned long long* __restrict__ lit1,
                                                        uint32_t split, double* __restrict__ accum, Counters* ctr) {
-    uint32_t p = blockIdx.x * kBlock + threadIdx.x;
-    if (p >= fr.n_tile_pixels) return;
+    // one thread per pixel, in slot order: a wave's 64 bits of a frame are then one or two words of
+    // Sample3::lit and its radiance reads are contiguous
+    const uint32_t slot_in_frame = blockIdx.x * kBlock + threadIdx.x;
+    if (slot_in_frame >= fr.n_tile_pixels) return;
     uint32_t n_lit = 0;
-    uint32_t ty = fdiv(p, fr.div_tile_w), tx = p - ty * fr.tile_w;
+    uint32_t ty, tx;
+    slot_pixel(fr, slot_in_frame, tx, ty);
     size_t pix = (size_t)(fr.y0 + ty) * fr.width + fr.x0 + tx;
     double r = accum[pix * 3], g = accum[pix * 3 + 1], b = accum[pix * 3 + 2];
     bool drop = (fr.flags & PT_FLAG_DROP_NONFINITE) != 0;
-    const uint32_t slot_in_frame = pixel_slot(fr, tx, ty);
     for (uint32_t s = 0; s < fr.n_samples; ++s) {
         size_t k = (size_t)s * fr.n_tile_pixels + slot_in_frame;
         size_t kl = s < split ? k : k - (size_t)split * fr.n_tile_pixels;  // slot within its lane
