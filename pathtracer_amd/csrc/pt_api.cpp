@@ -608,6 +608,10 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
         dv.eye_nodes = s->d_eye_nodes.as<ptd::EyeNode>();
         dv.eye_tris = s->d_eye_tris.as<ptd::EyeTri>();
     }
+    dv.n_mats = d->n_mats;
+    dv.lds_scene = dv.eye_nodes && dv.n_nodes <= (uint32_t)ptd::kLdsScene && d->n_tris <= (uint32_t)ptd::kLdsScene &&
+                   d->n_mats <= (uint32_t)ptd::kLdsMats && d->n_prims == 0;
+    if (const char* e = getenv("PT_LDS_SCENE")) dv.lds_scene = dv.lds_scene && atoi(e) != 0;
     HIP_TRY(hipDeviceSynchronize());
     for (int a = 0; a < 3; ++a) dv.background[a] = d->background[a];
 

@@ -74,6 +74,7 @@ struct EyeTri {
 };
 constexpr uint32_t kEyeTableMaxTris = 1u << 16;
 constexpr uint32_t kMaxCullEmitters = 8;
+constexpr int kLdsScene = 32, kLdsMats = 16;  // nodes / triangles / materials of a scene that the fused kernel holds in LDS
 // An emissive triangle as the last-bounce cull tests it: the origin-independent part of the
 // triangle test (v0, e0, e1, e0 x e1 in f64), computed once on the device by the test's own code.
 struct EmitTri {
@@ -128,6 +129,8 @@ struct Scene {
     // scheduled ranges of wave_rays rays per wave, or one ray per lane
     uint8_t vote_primary, vote_secondary, vote_shadow;
     uint8_t fuse;  // extend + shade of a bounce in one kernel where its rays go one per lane
+    uint8_t lds_scene;  // the scene is small enough to live in LDS inside the fused kernel (k_path LDS)
+    uint32_t n_mats;
     uint8_t fuse_shadow;  // ... and the bounce's light sample traced in that kernel too
     uint32_t wave_rays;
     uint32_t n_cu;  // compute units of the device (size of a persistent launch)

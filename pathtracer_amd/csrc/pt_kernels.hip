@@ -163,6 +163,11 @@ static void launch_path_t(bool nee, dim3 g, dim3 b, hipStream_t st, const Scene&
                           Queue in, Live live, Queue out, Push out_push, ShadowQueue sq, Push sq_push, Sample3 ls,
                           Counters* ctr) {
 #define PT_PATHK(N, M) hipLaunchKernelGGL((k_path<DEPTH, FIRST, LAST, N, M>), g, b, 0, st, sc, fr, bounce, in, live, out, out_push, sq, sq_push, ls, ctr)
+    if (DEPTH == 8 && !LAST && sc.lds_scene && (sc.mat_features & 3u) == 0) {  // tiny scene held in LDS
+        if (nee) hipLaunchKernelGGL((k_path<8, FIRST, false, true, 0, true>), g, b, 0, st, sc, fr, bounce, in, live, out, out_push, sq, sq_push, ls, ctr);
+        else hipLaunchKernelGGL((k_path<8, FIRST, false, false, 0, true>), g, b, 0, st, sc, fr, bounce, in, live, out, out_push, sq, sq_push, ls, ctr);
+        return;
+    }
     switch (sc.mat_features & 3u) {
         case 0: if (nee) PT_PATHK(true, 0); else PT_PATHK(false, 0); break;
         case 1: if (nee) PT_PATHK(true, 1); else PT_PATHK(false, 1); break;

@@ -755,14 +755,39 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
 #define PT_PATH_BLOCK_DEEP 64
 #endif
 template <int DEPTH> struct PathBlock { static constexpr int value = DEPTH <= 8 ? 128 : PT_PATH_BLOCK_DEEP; };
-template <int DEPTH, bool FIRST, bool LAST, bool NEE, int MATS>
-__global__ __launch_bounds__(PathBlock<DEPTH>::value) void k_path(Scene sc, Frame fr, uint32_t bounce, Queue in, Live live, Queue out,
+// LDS = the whole scene lives in LDS for the workgroup's lifetime (Scene::lds_scene: at most
+// kLdsScene nodes, triangles and kLdsMats materials - every scene of the reference): nodes, triangles,
+// shading records, materials and, for the primary bounce, the eye-relative tables are copied in by
+// the first live block (~6 KB, 48 B per thread) and every dependent fetch of the traversal becomes a
+// ds_read instead of a trip through the vector L1.
+constexpr int kMatWords = (int)(sizeof(Material) / sizeof(double));
+template <int DEPTH, bool FIRST, bool LAST, bool NEE, int MATS, bool LDS = false>
+__global__ __launch_bounds__(PathBlock<DEPTH>::value) void k_path(Scene gsc, Frame fr, uint32_t bounce, Queue in, Live live, Queue out,
                                                  Push out_push, ShadowQueue sq, Push sq_push, Sample3 ls,
                                                  Counters* ctr) {
     constexpr int kPathBlock = PathBlock<DEPTH>::value;
     __shared__ int stack[DEPTH * kPathBlock];
     __shared__ uint32_t lds_a[kPathBlock / 64 + 1];
     __shared__ uint32_t lds_b[kPathBlock / 64 + 1];
+    __shared__ float4 s_nodes[LDS ? kLdsScene * 4 : 1];
+    __shared__ float4 s_tris[LDS ? kLdsScene * 3 : 1];
+    __shared__ float4 s_shade[LDS ? kLdsScene * 2 : 1];
+    __shared__ double s_mats[LDS ? kLdsMats * kMatWords : 1];
+    __shared__ float4 s_eye_nodes[(LDS && FIRST) ? kLdsScene * 7 : 1];
+    __shared__ float4 s_eye_tris[(LDS && FIRST) ? kLdsScene * 7 : 1];
+    static_assert(sizeof(TriShade) == 32 && sizeof(EyeNode) == 112 && sizeof(EyeTri) == 112 && sizeof(Material) % 8 == 0, "LDS copies");
+    Scene sc = gsc;
+    if (LDS) {  // pointers first (compile-time: the address space is then known at every use), data below
+        sc.nodes = s_nodes;
+        sc.tris = s_tris;
+        sc.tri_shade = reinterpret_cast<const TriShade*>(s_shade);
+        sc.mats = reinterpret_cast<const Material*>(s_mats);
+        if (FIRST) {
+            sc.eye_nodes = reinterpret_cast<const EyeNode*>(s_eye_nodes);
+            sc.eye_tris = reinterpret_cast<const EyeTri*>(s_eye_tris);
+        }
+    }
+    bool scene_copied = false;
     if (ctr && blockIdx.x == 0 && threadIdx.x == 0)
         atomicAdd(&ctr->rays, FIRST ? (unsigned long long)fr.n_on_screen * fr.n_samples : live_total(live));
     ShadeOut r;
@@ -782,6 +807,22 @@ __global__ __launch_bounds__(PathBlock<DEPTH>::value) void k_path(Scene sc, Fram
             end = min(begin + kPathBlock, live.n);
         }
         if (begin >= end) return;
+        if (LDS && !scene_copied) {  // block-uniform: every thread of a live block gets here
+            const float4* g_shade = reinterpret_cast<const float4*>(gsc.tri_shade);
+            const double* g_mats = reinterpret_cast<const double*>(gsc.mats);
+            for (uint32_t k = threadIdx.x; k < gsc.n_nodes * 4; k += kPathBlock) s_nodes[k] = gsc.nodes[k];
+            for (uint32_t k = threadIdx.x; k < gsc.n_tris * 3; k += kPathBlock) s_tris[k] = gsc.tris[k];
+            for (uint32_t k = threadIdx.x; k < gsc.n_tris * 2; k += kPathBlock) s_shade[k] = g_shade[k];
+            for (uint32_t k = threadIdx.x; k < gsc.n_mats * kMatWords; k += kPathBlock) s_mats[k] = g_mats[k];
+            if (FIRST) {
+                const float4* g_en = reinterpret_cast<const float4*>(gsc.eye_nodes);
+                const float4* g_et = reinterpret_cast<const float4*>(gsc.eye_tris);
+                for (uint32_t k = threadIdx.x; k < gsc.n_nodes * 7; k += kPathBlock) s_eye_nodes[k] = g_en[k];
+                for (uint32_t k = threadIdx.x; k < gsc.n_tris * 7; k += kPathBlock) s_eye_tris[k] = g_et[k];
+            }
+            __syncthreads();
+            scene_copied = true;
+        }
         const uint32_t i = begin + threadIdx.x;
         if (i < end) {
             D3 o = mk(0., 0., 0.), d = o;
@@ -806,7 +847,7 @@ __global__ __launch_bounds__(PathBlock<DEPTH>::value) void k_path(Scene sc, Fram
             uint32_t nn = 0, nt = 0;
             uint32_t leaf = PT_MISS;
             if (on_screen)
-                leaf = (FIRST && sc.eye_nodes) ? traverse_eye<DEPTH, kPathBlock>(sc, d, 1e-5, t, stack + threadIdx.x)
+                leaf = (FIRST && (LDS || sc.eye_nodes)) ? traverse_eye<DEPTH, kPathBlock>(sc, d, 1e-5, t, stack + threadIdx.x)
                                                : traverse<DEPTH, false, false, kPathBlock>(sc, o, d, 1e-5, t, stack + threadIdx.x, nn, nt);
             shade_vertex<FIRST, LAST, NEE, MATS, true>(sc, fr, bounce, in, i, rec, leaf, t, o, d, ls, r);
             if (NEE && !LAST && sc.fuse_shadow && r.shadow) {

@@ -424,9 +424,13 @@ def test_eye_tables_are_bitwise_identical(gpu, monkeypatch, name):
     general = pt.Scene(data, gpu)
     monkeypatch.delenv("PT_EYE_TABLES")
     tables = pt.Scene(data, gpu)
+    monkeypatch.setenv("PT_LDS_SCENE", "0")          # tables read from global memory, not from the LDS copy
+    from_global = pt.Scene(data, gpu)
+    monkeypatch.delenv("PT_LDS_SCENE")
     for cfg in (pt.Config(width=211, height=97, samples_pr_pixel=3, bounces=2, seed=5, drop_nonfinite=True),
                 pt.Config(dim=64, samples_pr_pixel=2, bounces=0, seed=1, nee=True, drop_nonfinite=True)):
         assert general.render(cfg).tobytes() == tables.render(cfg).tobytes(), (name, cfg)
+        assert from_global.render(cfg).tobytes() == tables.render(cfg).tobytes(), (name, cfg)
 
 
 @pytest.mark.parametrize("name", ["CornellBox", "Test", "glossy_planes", "heightfield40"])
