@@ -188,7 +188,9 @@ bool launch_path(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, Li
     if (!live.n) return true;
     bool nee = (fr.flags & PT_FLAG_NEE) != 0 && sc.n_lights > 0;
     bool first = bounce == 0, last = bounce >= fr.max_bounces;
-    const uint32_t kPathBlock = sc.bvh_depth <= 8 ? PathBlock<8>::value : PathBlock<32>::value;
+    // the variant launch_path_t picks: the scene-in-LDS kernel has its own workgroup size
+    const bool lds = sc.bvh_depth <= 8 && !last && sc.lds_scene && (sc.mat_features & 3u) == 0;
+    const uint32_t kPathBlock = lds ? PathBlock<8, true>::value : (sc.bvh_depth <= 8 ? PathBlock<8>::value : PathBlock<32>::value);
     dim3 g(live.counts ? (live.n + kPathBlock - 1) / kPathBlock : trav_blocks(live.n, kPathBlock)), b(kPathBlock);
     if (last && !first && live.counts && sc.cull_last) {  // the queue after the cull: a few percent full
         live.sparse = 1;

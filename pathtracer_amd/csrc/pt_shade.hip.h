@@ -754,7 +754,11 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
 #ifndef PT_PATH_BLOCK_DEEP
 #define PT_PATH_BLOCK_DEEP 64
 #endif
-template <int DEPTH> struct PathBlock { static constexpr int value = DEPTH <= 8 ? 128 : PT_PATH_BLOCK_DEEP; };
+// (with the scene in LDS - LDS below - 256 threads: 64 / 128 / 256 / 512 / 1024 -> 19.5 / 24.0 / 25.5 /
+// 24.0 / 17.4 Gsamples/s on CornellBox; the copy is shared by twice the rays)
+template <int DEPTH, bool LDS = false> struct PathBlock {
+    static constexpr int value = DEPTH <= 8 ? (LDS ? 256 : 128) : PT_PATH_BLOCK_DEEP;
+};
 // LDS = the whole scene lives in LDS for the workgroup's lifetime (Scene::lds_scene: at most
 // kLdsScene nodes, triangles and kLdsMats materials - every scene of the reference): nodes, triangles,
 // shading records, materials and, for the primary bounce, the eye-relative tables are copied in by
@@ -762,10 +766,10 @@ template <int DEPTH> struct PathBlock { static constexpr int value = DEPTH <= 8 
 // ds_read instead of a trip through the vector L1.
 constexpr int kMatWords = (int)(sizeof(Material) / sizeof(double));
 template <int DEPTH, bool FIRST, bool LAST, bool NEE, int MATS, bool LDS = false>
-__global__ __launch_bounds__(PathBlock<DEPTH>::value) void k_path(Scene gsc, Frame fr, uint32_t bounce, Queue in, Live live, Queue out,
+__global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value)) void k_path(Scene gsc, Frame fr, uint32_t bounce, Queue in, Live live, Queue out,
                                                  Push out_push, ShadowQueue sq, Push sq_push, Sample3 ls,
                                                  Counters* ctr) {
-    constexpr int kPathBlock = PathBlock<DEPTH>::value;
+    constexpr int kPathBlock = PathBlock<DEPTH, LDS>::value;
     __shared__ int stack[DEPTH * kPathBlock];
     __shared__ uint32_t lds_a[kPathBlock / 64 + 1];
     __shared__ uint32_t lds_b[kPathBlock / 64 + 1];
