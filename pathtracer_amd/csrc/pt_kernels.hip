@@ -163,11 +163,17 @@ static void launch_path_t(bool nee, dim3 g, dim3 b, hipStream_t st, const Scene&
                           Queue in, Live live, Queue out, Push out_push, ShadowQueue sq, Push sq_push, Sample3 ls,
                           Counters* ctr) {
 #define PT_PATHK(N, M) hipLaunchKernelGGL((k_path<DEPTH, FIRST, LAST, N, M>), g, b, 0, st, sc, fr, bounce, in, live, out, out_push, sq, sq_push, ls, ctr)
-    if (DEPTH == 8 && !LAST && sc.lds_scene && (sc.mat_features & 3u) == 0) {  // tiny scene held in LDS
-        if (nee) hipLaunchKernelGGL((k_path<8, FIRST, false, true, 0, true>), g, b, 0, st, sc, fr, bounce, in, live, out, out_push, sq, sq_push, ls, ctr);
-        else hipLaunchKernelGGL((k_path<8, FIRST, false, false, 0, true>), g, b, 0, st, sc, fr, bounce, in, live, out, out_push, sq, sq_push, ls, ctr);
+#define PT_PATHL(N, M) hipLaunchKernelGGL((k_path<8, FIRST, false, N, M, true>), g, b, 0, st, sc, fr, bounce, in, live, out, out_push, sq, sq_push, ls, ctr)
+    if (DEPTH == 8 && !LAST && sc.lds_scene) {  // tiny scene held in LDS
+        switch (sc.mat_features & 3u) {
+            case 0: if (nee) PT_PATHL(true, 0); else PT_PATHL(false, 0); break;
+            case 1: if (nee) PT_PATHL(true, 1); else PT_PATHL(false, 1); break;
+            case 2: if (nee) PT_PATHL(true, 2); else PT_PATHL(false, 2); break;
+            default: if (nee) PT_PATHL(true, 3); else PT_PATHL(false, 3);
+        }
         return;
     }
+#undef PT_PATHL
     switch (sc.mat_features & 3u) {
         case 0: if (nee) PT_PATHK(true, 0); else PT_PATHK(false, 0); break;
         case 1: if (nee) PT_PATHK(true, 1); else PT_PATHK(false, 1); break;
@@ -189,7 +195,7 @@ bool launch_path(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, Li
     bool nee = (fr.flags & PT_FLAG_NEE) != 0 && sc.n_lights > 0;
     bool first = bounce == 0, last = bounce >= fr.max_bounces;
     // the variant launch_path_t picks: the scene-in-LDS kernel has its own workgroup size
-    const bool lds = sc.bvh_depth <= 8 && !last && sc.lds_scene && (sc.mat_features & 3u) == 0;
+    const bool lds = sc.bvh_depth <= 8 && !last && sc.lds_scene;
     const uint32_t kPathBlock = lds ? PathBlock<8, true>::value : (sc.bvh_depth <= 8 ? PathBlock<8>::value : PathBlock<32>::value);
     dim3 g(live.counts ? (live.n + kPathBlock - 1) / kPathBlock : trav_blocks(live.n, kPathBlock)), b(kPathBlock);
     if (last && !first && live.counts && sc.cull_last) {  // the queue after the cull: a few percent full
