@@ -814,8 +814,12 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value)) void k_path(Scene g
         if (LDS && !scene_copied) {  // block-uniform: every thread of a live block gets here
             const float4* g_shade = reinterpret_cast<const float4*>(gsc.tri_shade);
             const double* g_mats = reinterpret_cast<const double*>(gsc.mats);
-            for (uint32_t k = threadIdx.x; k < gsc.n_nodes * 4; k += kPathBlock) s_nodes[k] = gsc.nodes[k];
-            for (uint32_t k = threadIdx.x; k < gsc.n_tris * 3; k += kPathBlock) s_tris[k] = gsc.tris[k];
+            // (the primary bounce walks the eye tables; it needs the general arrays only for shadow rays and uvs)
+            constexpr bool kGeneral = !FIRST || NEE || (MATS & 1);
+            if (kGeneral) {
+                for (uint32_t k = threadIdx.x; k < gsc.n_nodes * 4; k += kPathBlock) s_nodes[k] = gsc.nodes[k];
+                for (uint32_t k = threadIdx.x; k < gsc.n_tris * 3; k += kPathBlock) s_tris[k] = gsc.tris[k];
+            }
             for (uint32_t k = threadIdx.x; k < gsc.n_tris * 2; k += kPathBlock) s_shade[k] = g_shade[k];
             for (uint32_t k = threadIdx.x; k < gsc.n_mats * kMatWords; k += kPathBlock) s_mats[k] = g_mats[k];
             if (FIRST) {
