@@ -904,18 +904,31 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(Frame fr, Sample3 ls, con
     size_t pix = (size_t)(fr.y0 + ty) * fr.width + fr.x0 + tx;
     double r = accum[pix * 3], g = accum[pix * 3 + 1], b = accum[pix * 3 + 2];
     bool drop = (fr.flags & PT_FLAG_DROP_NONFINITE) != 0;
-    for (uint32_t s = 0; s < fr.n_samples; ++s) {
-        size_t k = (size_t)s * fr.n_tile_pixels + slot_in_frame;
-        size_t kl = s < split ? k : k - (size_t)split * fr.n_tile_pixels;  // slot within its lane
-        const unsigned long long word = (s < split ? ls.lit : lit1)[kl >> 6];
-        double cr = 0., cg = 0., cb = 0.;  // a sample without a value is +0 (Sample3)
-        if (word >> (kl & 63u) & 1ull) {
-            const double* c = ls.c + k * 3;
-            cr = c[0]; cg = c[1]; cb = c[2];
-            ++n_lit;
+    // frames in index order; the bitmap words of eight frames are fetched together (independent loads),
+    // the rare radiance values behind them as they come
+    constexpr uint32_t kGroup = 8;
+    for (uint32_t s0 = 0; s0 < fr.n_samples; s0 += kGroup) {
+        unsigned long long word[kGroup];
+#pragma unroll
+        for (uint32_t j = 0; j < kGroup; ++j) {
+            const uint32_t s = min(s0 + j, fr.n_samples - 1u);
+            const size_t k = (size_t)s * fr.n_tile_pixels + slot_in_frame;
+            const size_t kl = s < split ? k : k - (size_t)split * fr.n_tile_pixels;  // slot within its lane
+            word[j] = (s < split ? ls.lit : lit1)[kl >> 6] >> (kl & 63u);
         }
-        if (drop && !(isfinite(cr) && isfinite(cg) && isfinite(cb))) continue;
-        r += cr; g += cg; b += cb;
+#pragma unroll
+        for (uint32_t j = 0; j < kGroup; ++j) {
+            const uint32_t s = s0 + j;
+            if (s >= fr.n_samples) break;
+            double cr = 0., cg = 0., cb = 0.;  // a sample without a value is +0 (Sample3)
+            if (word[j] & 1ull) {
+                const double* c = ls.c + ((size_t)s * fr.n_tile_pixels + slot_in_frame) * 3;
+                cr = c[0]; cg = c[1]; cb = c[2];
+                ++n_lit;
+            }
+            if (drop && !(isfinite(cr) && isfinite(cg) && isfinite(cb))) continue;
+            r += cr; g += cg; b += cb;
+        }
     }
     accum[pix * 3] = r; accum[pix * 3 + 1] = g; accum[pix * 3 + 2] = b;
     if (ctr && n_lit) atomicAdd(&ctr->lit, (unsigned long long)n_lit);
