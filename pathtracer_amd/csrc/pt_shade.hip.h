@@ -745,8 +745,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
 // The ray stays in registers between the two stages and the hit record never exists in memory: per
 // secondary ray 76 B are read and at most 76 B written, against 48 + 12 (extend) + 12 + 76 (shade)
 // + 76 for the two-kernel form, and the FP64-bound traversal of one wave overlaps the HBM-bound
-// shading of its neighbours on the same SIMD.  One wave per workgroup; survivors are appended with
-// one atomic per wave to segment blockIdx % kSegs.
+// shading of its neighbours on the same SIMD.  Survivors are appended with one atomic per
+// workgroup to segment blockIdx % kSegs.
 // Workgroup size of the fused kernel: 128 threads for shallow trees (measured on CornellBox 1080p:
 // 64 -> 9.38, 128 -> 11.09, 256 -> 10.93, 512 -> 9.90 Gsamples/s: one-wave workgroups are bound by
 // workgroup dispatch when every wave is short), one wave for deep trees (waves differ 10x in length;
