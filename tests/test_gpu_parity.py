@@ -521,3 +521,35 @@ def test_thin_and_tiny_tiles_assemble_bitwise(scenes):
         assert acc.tobytes() == whole.tobytes(), (tw, th)
     ref = oracle.render(cfg)
     assert (np.abs(whole - ref) > 1e-9 * np.maximum(1.0, np.abs(ref))).mean() < 5e-3
+
+
+@pytest.mark.parametrize("n_tris", [31, 32, 33, 64])
+def test_lds_scene_boundary_sizes(gpu, monkeypatch, n_tris):
+    # the fused kernel keeps scenes of up to 32 nodes / triangles in LDS: sizes on both sides of the
+    # limit, LDS copy against global memory (bitwise) and against the oracle
+    rng = np.random.default_rng(n_tris)
+    c = rng.uniform(-1.0, 1.0, (n_tris, 1, 3)) * [1.0, 1.0, 0.3] + [0.0, 0.0, 3.0]
+    verts = (c + rng.normal(0.0, 0.35, (n_tris, 3, 3))).reshape(-1, 3).astype(np.float32)
+    tris = np.arange(3 * n_tris, dtype=np.uint32).reshape(-1, 3)
+    mats = np.zeros(3, pt.MATERIAL_DTYPE)
+    mats["tex"] = -1
+    mats["color"][0], mats["color"][1] = [0.7, 0.6, 0.5], [0.2, 0.5, 0.8]
+    mats["emission"][2] = [5.0, 4.0, 3.0]
+    tri_mat = (np.arange(n_tris) % 3).astype(np.uint32)
+    cam = pt.Camera((0.0, 0.0, 0.0), (0.0, 0.0, 1.0), (0.0, 1.0, 0.0), 1.2)
+    data = pt.SceneData(verts, tris, tri_mat, mats, camera=cam)
+    scene, oracle = pt.Scene(data, gpu), O.OracleScene(data)
+    monkeypatch.setenv("PT_LDS_SCENE", "0")
+    from_global = pt.Scene(data, gpu)
+    monkeypatch.delenv("PT_LDS_SCENE")
+    for cfg in (pt.Config(width=96, height=64, samples_pr_pixel=4, bounces=3, seed=1),
+                pt.Config(width=96, height=64, samples_pr_pixel=3, bounces=2, seed=2, nee=True)):
+        img = scene.render(cfg)
+        assert img.tobytes() == from_global.render(cfg).tobytes()
+        ref = oracle.render(cfg)
+        assert ref.mean() > 1e-3
+        assert (np.abs(img - ref) > 1e-9 * np.maximum(1.0, np.abs(ref))).mean() < 5e-3
+    rays = oracle.generate_rays(pt.Config(width=96, height=64), 0)
+    tri, t = scene.trace_closest(rays)
+    rtri, rt = oracle.trace_closest(rays, use_bvh=False)
+    assert np.array_equal(tri, rtri) and np.array_equal(bits(t), bits(rt))
