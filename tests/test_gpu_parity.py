@@ -553,3 +553,27 @@ def test_lds_scene_boundary_sizes(gpu, monkeypatch, n_tris):
     tri, t = scene.trace_closest(rays)
     rtri, rt = oracle.trace_closest(rays, use_bvh=False)
     assert np.array_equal(tri, rtri) and np.array_equal(bits(t), bits(rt))
+
+
+def test_config2_converged_image_psnr(scenes):
+    # BASELINE.json configs[1] as named: CornellBox 1920x1080 at 1024 spp.  The converged image under
+    # identical per-pixel RNG streams against the oracle on a strided set of full rows: relative RMSE
+    # and the PSNR of the 8-bit resolve (main.rs:456-467, no gamma).  Stated tolerance: relative RMSE
+    # <= 1e-9 on the f64 sums, PSNR >= 80 dB (in fact every 8-bit value is equal).
+    data, scene, oracle = scenes["CornellBox"]
+    spp = 1024
+    cfg = pt.Config(width=1920, height=1080, samples_pr_pixel=spp, bounces=2, seed=1)
+    img = scene.render(cfg)
+    rows = list(range(11, 1080, 54))                       # 20 rows x 1920 px x 1024 spp = 39 M oracle samples
+    ref = np.zeros_like(img)
+    for y in rows:
+        oracle.render(cfg, ref, tile=(0, y, 1920, y + 1), threads=16)
+    a, b = img[rows], ref[rows]
+    assert b.mean() > 1.0                                   # sums of 1024 samples
+    rel_rmse = np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean())
+    assert rel_rmse <= 1e-9, rel_rmse
+    qa, qb = pt.resolve_rgb8(a, spp).astype(np.float64), pt.resolve_rgb8(b, spp).astype(np.float64)
+    mse = ((qa - qb) ** 2).mean()
+    psnr = np.inf if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+    assert psnr >= 80.0, psnr
+    assert np.array_equal(qa, qb)
