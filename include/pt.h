@@ -216,6 +216,14 @@ int pt_bvh_build(const float* verts, uint32_t n_verts, const uint32_t* tris, uin
                  uint32_t max_leaf, pt_bvh_node* nodes_out, uint32_t cap_nodes,
                  uint32_t* n_nodes_out, uint32_t* order_out, uint32_t* max_depth_out);
 
+/* ---- bvh.rs:17-21 when the host keeps its own builder (north_star: "BVH build in bvh.rs"): checks
+ * everything the traversal kernels assume of a caller-supplied tree before pt_scene_create takes it
+ * (child indices in range, each inner node reached once, leaf runs inside [0, n_tris) and covering
+ * every triangle exactly once, tri_order a permutation, depth within the kernels' 32-entry LDS
+ * stack — a deeper tree is PT_ERR_UNSUPPORTED, never silently truncated).  Host only, no device. */
+int pt_bvh_validate(const pt_bvh_node* nodes, uint32_t n_nodes, const uint32_t* tri_order, uint32_t n_tris,
+                    uint32_t* max_depth_out);
+
 /* ---- scene.rs:61 Scene::trace_closest on an explicit ray set (the extend kernel alone).
  * tri_id[i] = global triangle id (desc order), PT_PRIM_BASE + k for primitive k, or PT_MISS; t[i] = hit distance (unchanged t_max on a miss).
  * Tie rule for bit-identical t: lowest triangle id. */

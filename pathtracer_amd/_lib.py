@@ -96,6 +96,7 @@ PROTOTYPES = {
     "pt_scene_get_bvh": (C.c_int, [_vp, _P(_P(pt_bvh_node)), _P(C.c_uint32), _P(_P(C.c_uint32)), _P(C.c_uint32)]),
     "pt_bvh_build": (C.c_int, [_P(C.c_float), C.c_uint32, _P(C.c_uint32), C.c_uint32, C.c_uint32,
                                _P(pt_bvh_node), C.c_uint32, _P(C.c_uint32), _P(C.c_uint32), _P(C.c_uint32)]),
+    "pt_bvh_validate": (C.c_int, [_P(pt_bvh_node), C.c_uint32, _P(C.c_uint32), C.c_uint32, _P(C.c_uint32)]),
     "pt_trace_closest": (C.c_int, [_vp, _P(pt_ray), C.c_size_t, _P(C.c_uint32), _P(C.c_double)]),
     "pt_generate_rays": (C.c_int, [_vp, _P(pt_render_params), C.c_uint64, _P(pt_ray)]),
     "pt_sample_brdf": (C.c_int, [_vp, _P(pt_ray), _P(C.c_uint32), _P(C.c_double), _P(C.c_uint32), C.c_size_t,

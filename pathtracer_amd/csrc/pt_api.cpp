@@ -9,6 +9,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -161,6 +162,8 @@ struct pt_scene {
     std::vector<DevBuf*> d_texels;
     Workspace ws;
     std::mutex mu;
+    std::mutex host_mu;   // pt_render: the cached device copy of the caller's host buffer
+    DevBuf d_host_accum;
     int profiling = 0;
     pt_stats stats{};
     std::vector<TimedLaunch> timed;
@@ -169,9 +172,13 @@ struct pt_scene {
     int persistent = 1;             // vote-scheduled launches claim their ranges from work cursors
     int screen_cull = 1;            // primary rays outside the scene's screen bounds are not generated
     hipStream_t side = nullptr;     // the second lane's stream
+    hipEvent_t ws_free = nullptr;   // recorded at the end of every pt_render_device call: the workspace is free again
+    bool ws_used = false;
+    bool timers_off = false;        // set for the duration of a pt_render_device_noalloc call (no event creation)
     std::vector<hipEvent_t> sync;   // cross-stream ordering events (no timing)
     ~pt_scene() {
         if (side) (void)hipStreamDestroy(side);
+        if (ws_free) (void)hipEventDestroy(ws_free);
         for (auto e : sync) (void)hipEventDestroy(e);
         for (auto* b : d_texels) delete b;
         for (auto e : event_pool) (void)hipEventDestroy(e);
@@ -266,7 +273,7 @@ struct Timer {  // optional HIP-event bracket around one kernel launch
     int kind;
     bool on;
     hipEvent_t a{}, b{};
-    Timer(pt_scene* s_, hipStream_t st_, int kind_) : s(s_), st(st_), kind(kind_), on(s_->profiling >= 1) {
+    Timer(pt_scene* s_, hipStream_t st_, int kind_) : s(s_), st(st_), kind(kind_), on(s_->profiling >= 1 && !s_->timers_off) {
         if (!on) return;
         auto get = [&](hipEvent_t& e) {
             if (!s->event_pool.empty()) { e = s->event_pool.back(); s->event_pool.pop_back(); return true; }
@@ -349,6 +356,22 @@ int pt_bvh_build(const float* verts, uint32_t n_verts, const uint32_t* tris, uin
     return PT_OK;
 }
 
+int pt_bvh_validate(const pt_bvh_node* nodes, uint32_t n_nodes, const uint32_t* tri_order, uint32_t n_tris,
+                    uint32_t* max_depth_out) {
+    if ((n_tris && (!nodes || !tri_order))) { set_error("null argument"); return PT_ERR_INVALID; }
+    std::string why;
+    uint32_t depth = 0;
+    int rc = pth::bvh_validate(nodes, n_nodes, tri_order, n_tris, (uint32_t)ptd::kStackDepth, depth, why);
+    if (rc != PT_OK) { set_error("invalid BVH: %s", why.c_str()); return rc; }
+    std::vector<uint8_t> seen(n_tris, 0);
+    for (uint32_t i = 0; i < n_tris; ++i) {
+        if (seen[tri_order[i]]) { set_error("invalid BVH: triangle %u listed twice", tri_order[i]); return PT_ERR_INVALID; }
+        seen[tri_order[i]] = 1;
+    }
+    if (max_depth_out) *max_depth_out = depth;
+    return PT_OK;
+}
+
 int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
     if (!d || !out) { set_error("null argument"); return PT_ERR_INVALID; }
     *out = nullptr;
@@ -406,17 +429,10 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
         int rc = pth::bvh_build(d->verts, d->n_verts, d->tris, d->n_tris, max_leaf, s->nodes, s->order, s->depth);
         if (rc != PT_OK) { set_error("bvh build failed (non-finite vertex?)"); return rc; }
     }
-    {
-        std::string why;
+    {   // the traversal kernels trust the tree (indices, leaf runs, depth <= their LDS stack): check it all
         uint32_t depth = 0;
-        int rc = pth::bvh_validate(s->nodes.data(), (uint32_t)s->nodes.size(), s->order.data(), d->n_tris,
-                                   (uint32_t)ptd::kStackDepth, depth, why);
-        if (rc != PT_OK) { set_error("invalid BVH: %s", why.c_str()); return rc; }
-        std::vector<uint8_t> seen(d->n_tris, 0);
-        for (uint32_t i = 0; i < d->n_tris; ++i) {
-            if (seen[s->order[i]]) { set_error("invalid BVH: triangle %u listed twice", s->order[i]); return PT_ERR_INVALID; }
-            seen[s->order[i]] = 1;
-        }
+        int rc = pt_bvh_validate(s->nodes.data(), (uint32_t)s->nodes.size(), s->order.data(), d->n_tris, &depth);
+        if (rc != PT_OK) return rc;
         s->depth = depth;
     }
 
@@ -543,6 +559,7 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
 
     HIP_TRY(s->d_ctr.alloc(sizeof(ptd::Counters)));
     HIP_TRY(hipMemset(s->d_ctr.p, 0, sizeof(ptd::Counters)));
+    HIP_TRY(hipEventCreateWithFlags(&s->ws_free, hipEventDisableTiming));
 
     ptd::Scene& dv = s->dev;
     dv.nodes = s->d_nodes.as<float4>();
@@ -716,50 +733,19 @@ void screen_bounds(const pt_scene* s, uint32_t width, uint32_t height, ptd::Fram
 }
 }  // namespace
 
-int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, void* stream) {
-    if (!s || !accum_dev) { set_error("null argument"); return PT_ERR_INVALID; }
-    int rc = check_params(P);
-    if (rc != PT_OK) return rc;
-    if (P->sample_count == 0) return PT_OK;
-    std::lock_guard<std::mutex> lk(s->mu);
-    DeviceGuard guard(s->device);
-    if (!guard.ok) { set_error("hipSetDevice(%d) failed", s->device); return PT_ERR_DEVICE; }
-    hipStream_t st = (hipStream_t)stream;
+}  // extern "C"
 
+namespace {
+// The wavefront loop of one render call: batches of `spp` frames over the workspace `w` (the scene's
+// own, or the static one of pt_render_device_noalloc), `jitter` = room for spp frame jitters.
+// Enqueues only: no allocation, no host synchronisation (with profiling on, event pairs come from
+// the scene's pool or are created, which is why the no-alloc entry point switches timers off).
+int render_batches(pt_scene* s, const pt_render_params* P, double* accum_dev, hipStream_t st, Workspace& w,
+                   double* jitter, uint32_t spp, bool two, bool nee, bool diffs) {
     const uint32_t tw = P->x1 - P->x0, th = P->y1 - P->y0;
     const uint32_t npix = tw * th;
-    const bool nee = (P->flags & PT_FLAG_NEE) != 0 && s->dev.n_lights > 0;
-    // differentials only feed texture filtering: without a texture (or a second vertex) nothing reads them
-    const bool diffs = (P->flags & PT_FLAG_PROPAGATE_DIFFS) && (P->flags & PT_FLAG_USE_DIFFS) && s->n_texs > 0 &&
-                       P->max_bounces > 0;
-    // Frames in flight per pass.  Every launch ends in a tail that does not shrink with the batch (the
-    // longest rays of the 10M-triangle scene take ~0.4 ms on their own; measured 0.30 + 0.47 ms per
-    // frame for its primary kernel at 4K), so batches are large: ~128M paths by default (~26 GB of
-    // queues out of 288), halved while the allocation does not fit.
-    uint32_t spp = P->spp_per_batch;
-    if (spp == 0) spp = std::max<uint32_t>(1u, (1u << 27) / npix);
-    spp = std::min(spp, P->sample_count);
-    spp = std::min<uint32_t>(spp, std::max<uint32_t>(1u, (1u << 30) / npix));
-    bool two = false;
-    for (;;) {
-        // two lanes when a batch has frames to split and enough paths for each half to fill the chip
-        two = s->pipeline != 0 && spp >= 2 && (uint64_t)(spp / 2) * npix >= kMinLanePaths;
-        const uint32_t lane_spp = two ? spp - spp / 2 : spp;
-        rc = ensure_workspace(s, spp * npix, lane_spp * npix, two ? 2 : 1, nee, diffs);
-        if (rc != PT_ERR_NOMEM || spp == 1 || P->spp_per_batch != 0) break;
-        spp = (spp + 1) / 2;
-    }
-    if (rc != PT_OK) return rc;
-    Workspace& w = s->ws;
-    if (two && (rc = ensure_side_stream(s, 2)) != PT_OK) return rc;
-    if (w.jitter_cap < P->sample_count) {
-        HIP_TRY(hipStreamSynchronize(st));
-        HIP_TRY(w.jitter.alloc((size_t)P->sample_count * 2 * sizeof(double)));
-        w.jitter_cap = P->sample_count;
-    }
-    // main.rs:402-405: one jitter pair per frame, scaled by the pixel size
-    ptd::launch_jitter(P->seed, P->sample_begin, P->sample_count, 1. / (double)P->width, 1. / (double)P->height,
-                       w.jitter.as<double>(), st);
+    int rc = PT_OK;
+    (void)rc;
     const bool stats = s->profiling >= 2;
     ptd::Counters* ctr = s->d_ctr.as<ptd::Counters>();
 
@@ -823,7 +809,10 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
         fr.max_bounces = P->max_bounces;
         fr.flags = diffs ? P->flags : (P->flags & ~(uint32_t)PT_FLAG_PROPAGATE_DIFFS);
         fr.diff_size = P->diff_size;
-        fr.jitter = w.jitter.as<double>() + (size_t)b0 * 2;
+        // main.rs:402-405: one jitter pair per frame, scaled by the pixel size (the batch's frames; the
+        // previous batch's kernels are ahead of this launch on `st`, and a second lane joins `st` below)
+        ptd::launch_jitter(P->seed, fr.sample_base, ns, 1. / (double)P->width, 1. / (double)P->height, jitter, st);
+        fr.jitter = jitter;
         screen_bounds(s, P->width, P->height, fr);
         ptd::finish_frame(fr);
         // the generate stage is fused into the bounce-0 extend and shade kernels (they rebuild the
@@ -880,6 +869,62 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
         }
         HIP_TRY(hipGetLastError());
     }
+    return PT_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, void* stream) {
+    if (!s || !accum_dev) { set_error("null argument"); return PT_ERR_INVALID; }
+    int rc = check_params(P);
+    if (rc != PT_OK) return rc;
+    if (P->sample_count == 0) return PT_OK;
+    std::lock_guard<std::mutex> lk(s->mu);
+    DeviceGuard guard(s->device);
+    if (!guard.ok) { set_error("hipSetDevice(%d) failed", s->device); return PT_ERR_DEVICE; }
+    hipStream_t st = (hipStream_t)stream;
+
+    const uint32_t tw = P->x1 - P->x0, th = P->y1 - P->y0;
+    const uint32_t npix = tw * th;
+    const bool nee = (P->flags & PT_FLAG_NEE) != 0 && s->dev.n_lights > 0;
+    // differentials only feed texture filtering: without a texture (or a second vertex) nothing reads them
+    const bool diffs = (P->flags & PT_FLAG_PROPAGATE_DIFFS) && (P->flags & PT_FLAG_USE_DIFFS) && s->n_texs > 0 &&
+                       P->max_bounces > 0;
+    // Frames in flight per pass.  Every launch ends in a tail that does not shrink with the batch (the
+    // longest rays of the 10M-triangle scene take ~0.4 ms on their own; measured 0.30 + 0.47 ms per
+    // frame for its primary kernel at 4K), so batches are large: ~128M paths by default (~26 GB of
+    // queues out of 288), halved while the allocation does not fit.
+    uint32_t spp = P->spp_per_batch;
+    if (spp == 0) spp = std::max<uint32_t>(1u, (1u << 27) / npix);
+    spp = std::min(spp, P->sample_count);
+    spp = std::min<uint32_t>(spp, std::max<uint32_t>(1u, (1u << 30) / npix));
+    // All renders of a scene share its workspace (queues, hit records, counters, per-sample radiance,
+    // jitter).  A call on another stream than the previous one must not start while that one's kernels
+    // still use it: every call ends by recording `ws_free` and begins by making its stream wait for it
+    // (a no-op on the same stream).  s->mu only orders the host-side enqueueing.
+    if (s->ws_used) HIP_TRY(hipStreamWaitEvent(st, s->ws_free, 0));
+    bool two = false;
+    for (;;) {
+        // two lanes when a batch has frames to split and enough paths for each half to fill the chip
+        two = s->pipeline != 0 && spp >= 2 && (uint64_t)(spp / 2) * npix >= kMinLanePaths;
+        const uint32_t lane_spp = two ? spp - spp / 2 : spp;
+        rc = ensure_workspace(s, spp * npix, lane_spp * npix, two ? 2 : 1, nee, diffs);
+        if (rc != PT_ERR_NOMEM || spp == 1 || P->spp_per_batch != 0) break;
+        spp = (spp + 1) / 2;
+    }
+    if (rc != PT_OK) return rc;
+    Workspace& w = s->ws;
+    if (two && (rc = ensure_side_stream(s, 2)) != PT_OK) return rc;
+    if (w.jitter_cap < spp) {
+        HIP_TRY(hipDeviceSynchronize());  // an earlier call (on any stream) may still read the old buffer
+        HIP_TRY(w.jitter.alloc((size_t)spp * 2 * sizeof(double)));
+        w.jitter_cap = spp;
+    }
+    rc = render_batches(s, P, accum_dev, st, w, w.jitter.as<double>(), spp, two, nee, diffs);
+    if (rc != PT_OK) return rc;
+    HIP_TRY(hipEventRecord(s->ws_free, st));
+    s->ws_used = true;
     s->stats.samples += (uint64_t)npix * P->sample_count;
     if (s->timed.size() >= kMaxPendingTimers) return collect_timers(s);
     return PT_OK;
@@ -892,13 +937,16 @@ int pt_render(pt_scene* s, const pt_render_params* P, double* accum_rgb) {
     DeviceGuard guard(s->device);
     if (!guard.ok) { set_error("hipSetDevice(%d) failed", s->device); return PT_ERR_DEVICE; }
     size_t n = (size_t)P->width * P->height * 3;
-    DevBuf acc;
-    hipError_t e = acc.alloc(n * sizeof(double));
-    if (e != hipSuccess) { set_error("accumulation buffer allocation failed: %s", hipGetErrorString(e)); return PT_ERR_NOMEM; }
+    std::lock_guard<std::mutex> lk(s->host_mu);  // one host-buffer render of a scene at a time: they share d_host_accum
+    DevBuf& acc = s->d_host_accum;               // kept between calls (a hipMalloc + hipFree per frame otherwise)
+    if (acc.bytes < n * sizeof(double)) {
+        hipError_t e = acc.alloc(n * sizeof(double));
+        if (e != hipSuccess) { set_error("accumulation buffer allocation failed: %s", hipGetErrorString(e)); return PT_ERR_NOMEM; }
+    }
     HIP_TRY(hipMemcpy(acc.p, accum_rgb, n * sizeof(double), hipMemcpyHostToDevice));
     rc = pt_render_device(s, P, acc.as<double>(), nullptr);
     if (rc != PT_OK) return rc;
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(nullptr));
     HIP_TRY(hipMemcpy(accum_rgb, acc.p, n * sizeof(double), hipMemcpyDeviceToHost));
     return PT_OK;
 }
@@ -977,9 +1025,14 @@ int pt_sample_brdf(pt_scene* s, const pt_ray* rays, const uint32_t* tri_id, cons
         set_error("null argument");
         return PT_ERR_INVALID;
     }
-    if (width == 0 || height == 0 || n >= (1ull << 31)) { set_error("bad argument"); return PT_ERR_INVALID; }
+    if (width == 0 || height == 0 || (uint64_t)width * height >= (1ull << 32) || n >= (1ull << 31)) {
+        set_error("bad argument");
+        return PT_ERR_INVALID;
+    }
     for (size_t i = 0; i < n; ++i) {
-        if (tri_id[i] >= s->n_tris) { set_error("ray %zu: triangle id out of range", i); return PT_ERR_INVALID; }
+        // a triangle id, or PT_PRIM_BASE + k for a hit on analytic primitive k (what pt_trace_closest returns)
+        const bool prim = tri_id[i] >= PT_PRIM_BASE && tri_id[i] - PT_PRIM_BASE < s->dev.n_prims;
+        if (tri_id[i] >= s->n_tris && !prim) { set_error("ray %zu: triangle id out of range", i); return PT_ERR_INVALID; }
         if (pixel[i] >= (uint64_t)width * height) { set_error("ray %zu: pixel out of range", i); return PT_ERR_INVALID; }
     }
     if (n == 0) return PT_OK;

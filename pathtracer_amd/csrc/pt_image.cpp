@@ -12,6 +12,7 @@
 #include <string>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 
 namespace pth {
 
@@ -50,6 +51,7 @@ int decode_png(const char* path, uint32_t& w, uint32_t& h, std::vector<uint8_t>&
         const uint8_t* type = &file[pos + 4];
         if (pos + 12 + (size_t)len > file.size()) { set_error("%s: truncated chunk", path); return PT_ERR_IO; }
         const uint8_t* data = &file[pos + 8];
+        if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), type, 4 + len) != be32(data + len)) { set_error("%s: chunk CRC mismatch", path); return PT_ERR_IO; }
         if (!std::memcmp(type, "IHDR", 4) && len >= 13) {
             w = be32(data); h = be32(data + 4); depth = data[8]; ctype = data[9]; interlace = data[12];
             have_ihdr = true;
@@ -74,6 +76,14 @@ int decode_png(const char* path, uint32_t& w, uint32_t& h, std::vector<uint8_t>&
         default: set_error("%s: bad colour type", path); return PT_ERR_UNSUPPORTED;
     }
     size_t stride = (size_t)w * ch;
+    // The IHDR is only a claim.  A deflate stream expands at most 1032:1, so the compressed data
+    // bounds the pixels the file can hold; a header that promises more is refused before anything of
+    // that size is allocated (a 100-byte file cannot make this allocate gigabytes).
+    if ((double)(stride + 1) * (double)h > 1032.0 * (double)idat.size() + 1024.0) {
+        set_error("%s: IHDR promises %ux%u pixels, the %zu compressed bytes cannot hold them", path, w, h, idat.size());
+        return PT_ERR_IO;
+    }
+    if (ctype == 3 && (plte.empty() || plte.size() % 3 != 0)) { set_error("%s: palette image without a valid PLTE chunk", path); return PT_ERR_IO; }
     std::vector<uint8_t> raw((stride + 1) * h);
     uLongf raw_len = (uLongf)raw.size();
     int zr = uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size());
@@ -113,8 +123,8 @@ int decode_png(const char* path, uint32_t& w, uint32_t& h, std::vector<uint8_t>&
         if (ctype == 0 || ctype == 4) { r = g = b = p[0]; }
         else if (ctype == 3) {
             size_t k = (size_t)p[0] * 3;
-            if (k + 2 < plte.size()) { r = plte[k]; g = plte[k + 1]; b = plte[k + 2]; }
-            else { r = g = b = 0; }
+            if (k + 2 >= plte.size()) { set_error("%s: palette index %u beyond the PLTE chunk", path, (unsigned)p[0]); return PT_ERR_IO; }
+            r = plte[k]; g = plte[k + 1]; b = plte[k + 2];
         } else { r = p[0]; g = p[1]; b = p[2]; }  // to_rgb() drops alpha (mipmap.rs:62)
         rgb8[3 * i] = r; rgb8[3 * i + 1] = g; rgb8[3 * i + 2] = b;
     }
@@ -170,7 +180,13 @@ extern "C" {
 int pt_decode_png(const char* path, uint32_t* width, uint32_t* height, uint8_t** rgb8_out) {
     if (!path || !width || !height || !rgb8_out) { pth::set_error("null argument"); return PT_ERR_INVALID; }
     std::vector<uint8_t> px;
-    int rc = pth::decode_png(path, *width, *height, px);
+    int rc;
+    try {
+        rc = pth::decode_png(path, *width, *height, px);
+    } catch (const std::bad_alloc&) {  // nothing may unwind across the C ABI
+        pth::set_error("%s: out of memory while decoding", path);
+        return PT_ERR_NOMEM;
+    }
     if (rc != PT_OK) return rc;
     uint8_t* out = (uint8_t*)std::malloc(px.size());
     if (!out) { pth::set_error("out of memory"); return PT_ERR_NOMEM; }

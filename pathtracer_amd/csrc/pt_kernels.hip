@@ -99,7 +99,7 @@ static void launch_extend_v(const Scene& sc, const Frame& fr, Queue q, const dou
     dim3 g(live.counts ? (live.n + br - 1) / br : trav_blocks(live.n, br)), b(kTravBlock);
     if (VOTE && live.cursors) g.x = min(g.x, persistent_blocks(sc));
     if (sc.bvh_depth <= 8) hipLaunchKernelGGL((k_extend<8, STATS, PRIMARY, VOTE>), g, b, 0, st, sc, fr, q, tmin, tmax, live, wr, hits, ctr);
-    else if (sc.bvh_depth <= 16 || getenv("PT_HACK16")) hipLaunchKernelGGL((k_extend<16, STATS, PRIMARY, VOTE>), g, b, 0, st, sc, fr, q, tmin, tmax, live, wr, hits, ctr);
+    else if (sc.bvh_depth <= 16) hipLaunchKernelGGL((k_extend<16, STATS, PRIMARY, VOTE>), g, b, 0, st, sc, fr, q, tmin, tmax, live, wr, hits, ctr);
     else hipLaunchKernelGGL((k_extend<32, STATS, PRIMARY, VOTE>), g, b, 0, st, sc, fr, q, tmin, tmax, live, wr, hits, ctr);
 }
 template <bool STATS, bool PRIMARY>

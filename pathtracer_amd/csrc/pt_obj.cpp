@@ -18,6 +18,7 @@
 #include <fstream>
 #include <map>
 #include <memory>
+#include <new>
 #include <sstream>
 #include <string>
 #include <tuple>
@@ -141,11 +142,24 @@ struct pt_model {
     pt_scene_desc desc;
 };
 
+static int load_obj_impl(const char* obj_path, uint32_t flags, pt_model** out);
+
 extern "C" {
 
 int pt_load_obj(const char* obj_path, uint32_t flags, pt_model** out) {
     if (!obj_path || !out) { set_error("null argument"); return PT_ERR_INVALID; }
     *out = nullptr;
+    try {
+        return load_obj_impl(obj_path, flags, out);
+    } catch (const std::bad_alloc&) {  // nothing may unwind across the C ABI (a huge or corrupt file)
+        set_error("%s: out of memory while loading", obj_path);
+        return PT_ERR_NOMEM;
+    }
+}
+
+}  // extern "C"
+
+static int load_obj_impl(const char* obj_path, uint32_t flags, pt_model** out) {
     std::ifstream f(obj_path);
     if (!f) { set_error("Failed to load %s", obj_path); return PT_ERR_IO; }  // obj.rs:16 panics
     const std::string dir = dir_of(obj_path);
@@ -345,6 +359,8 @@ int pt_load_obj(const char* obj_path, uint32_t flags, pt_model** out) {
     *out = M.release();
     return PT_OK;
 }
+
+extern "C" {
 
 const pt_scene_desc* pt_model_desc(const pt_model* m) { return m ? &m->desc : nullptr; }
 uint32_t pt_model_count(const pt_model* m) { return m ? (uint32_t)m->models.size() : 0; }

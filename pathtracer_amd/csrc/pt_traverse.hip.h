@@ -127,6 +127,19 @@ extern "C" int pt_debug_tail(unsigned long long* out) {
 }
 #endif
 constexpr int kDone = (int)0x80000000;
+// The LDS stack of a traversal holds DEPTH entries and DEPTH is instantiated from the scene's tree
+// depth (launchers: 8 / 16 / 32 >= Scene::bvh_depth; bvh_validate refuses deeper trees), so a push
+// can never find the stack full.  A build with -DPT_DEBUG_CHECKS counts any push that does, instead
+// of trusting that argument: pt_debug_stack_overflows() must read 0 after any render.
+#ifdef PT_DEBUG_CHECKS
+__device__ unsigned int g_stack_overflows;
+extern "C" int pt_debug_stack_overflows(unsigned int* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stack_overflows), sizeof(unsigned int));
+}
+#define PT_STACK_CHECK(sp, depth) do { if ((sp) >= (depth)) atomicAdd(&g_stack_overflows, 1u); } while (0)
+#else
+#define PT_STACK_CHECK(sp, depth) ((void)0)
+#endif
 template <int DEPTH, bool STATS, int STRIDE = kTravBlock>
 __device__ __forceinline__ int node_step(const Scene& sc, int cur, D3 o, D3 inv, double t_min, double t_max, int* stk,
                                          int& sp, uint32_t& n_nodes) {
@@ -142,6 +155,7 @@ __device__ __forceinline__ int node_step(const Scene& sc, int cur, D3 o, D3 inv,
     if (h0 && h1) {
         int nearc = c0, farc = c1;
         if (tn1 < tn0) { nearc = c1; farc = c0; }
+        PT_STACK_CHECK(sp, DEPTH);
         if (sp < DEPTH) { stk[sp * STRIDE] = farc; ++sp; }
         return nearc;
     }
@@ -375,6 +389,7 @@ __device__ __forceinline__ uint32_t traverse_eye(const Scene& sc, D3 d, double t
             if (h0 && h1) {
                 int nearc = c0, farc = c1;
                 if (tn1 < tn0) { nearc = c1; farc = c0; }
+                PT_STACK_CHECK(sp, DEPTH);
                 if (sp < DEPTH) { stk[sp * STRIDE] = farc; ++sp; }
                 cur = nearc;
             } else if (h0) cur = c0;

@@ -282,6 +282,29 @@ def test_two_lane_pipeline_is_bitwise_invariant(gpu, monkeypatch, nee):
     assert (np.abs(img - ref) > 1e-9 * np.maximum(1.0, np.abs(ref))).mean() < 1e-3
 
 
+def test_two_streams_share_one_scene(gpu):
+    # pt_render_device is asynchronous on the caller's stream, and every call on a scene uses the scene's
+    # one workspace: calls issued alternately on two streams must still not overlap on the device (each
+    # call waits for the event the previous one recorded).  Same bits as the one-stream renders.
+    import torch
+    torch.cuda.set_device(gpu)
+    scene = pt.Scene(pt.scene_data("CornellBox"), gpu)
+    cfg_a = pt.Config(width=1024, height=1024, bounces=2, seed=21)
+    cfg_b = pt.Config(width=768, height=512, bounces=3, seed=22, nee=True)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    acc_a = torch.zeros((cfg_a.h, cfg_a.w, 3), dtype=torch.float64, device="cuda")
+    acc_b = torch.zeros((cfg_b.h, cfg_b.w, 3), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    for i in range(6):
+        scene.render_device(cfg_a, acc_a.data_ptr(), 3 * i, 3, stream=s1.cuda_stream)
+        scene.render_device(cfg_b, acc_b.data_ptr(), 3 * i, 3, stream=s2.cuda_stream)
+    torch.cuda.synchronize()
+    ref_a = scene.render(cfg_a, sample_begin=0, sample_count=18)
+    ref_b = scene.render(cfg_b, sample_begin=0, sample_count=18)
+    assert acc_a.cpu().numpy().tobytes() == ref_a.tobytes()
+    assert acc_b.cpu().numpy().tobytes() == ref_b.tobytes()
+
+
 @pytest.mark.parametrize("name", ["CornellBox", "Test", "glossy_planes", "heightfield40"])
 def test_fused_path_kernel_is_bitwise_identical(gpu, monkeypatch, name):
     # extend+shade in one kernel (every bounce of a shallow tree, the primary bounce of a deep one)

@@ -285,3 +285,50 @@ def test_parallel_bvh_build_is_independent_of_thread_count(monkeypatch):
         out.append((nodes.tobytes(), order.tobytes(), depth))
     assert out[0] == out[1] == out[2]
     assert sorted(np.frombuffer(out[0][1], np.uint32).tolist()) == list(range(data.n_tris))
+
+
+# ---- caller-supplied trees (pt_bvh_validate): what the traversal kernels assume is checked on the host ----
+def _chain_tree(n_tris):
+    """A degenerate left-deep tree over n_tris triangles: inner node i = {leaf i, node i + 1}."""
+    nodes = np.zeros(n_tris - 1, pt.NODE_DTYPE)
+    nodes["bounds"][:, 0:3], nodes["bounds"][:, 3:6] = -1.0, 1.0
+    nodes["bounds"][:, 6:9], nodes["bounds"][:, 9:12] = -1.0, 1.0
+    for i in range(n_tris - 1):
+        nodes["child"][i, 0] = ~(i << 3)                       # leaf: one triangle, slot i
+        nodes["child"][i, 1] = i + 1 if i + 2 < n_tris else ~((i + 1) << 3)
+    return nodes, np.arange(n_tris, dtype=np.uint32)
+
+
+def _validate(nodes, order, n_tris):
+    depth = C.c_uint32()
+    rc = L.lib.pt_bvh_validate(C.cast(nodes.ctypes.data, C.POINTER(L.pt_bvh_node)), len(nodes),
+                               order.ctypes.data_as(C.POINTER(C.c_uint32)), n_tris, C.byref(depth))
+    return rc, depth.value, (L.lib.pt_last_error() or b"").decode()
+
+
+def test_tree_deeper_than_the_traversal_stack_is_refused():
+    # the kernels' LDS stack has 32 entries per lane and a push beyond it would be dropped (geometry
+    # silently missing): such a tree must never reach them
+    nodes, order = _chain_tree(33)                             # 32 inner levels: fits exactly
+    rc, depth, _ = _validate(nodes, order, 33)
+    assert rc == L.PT_OK and depth == 32
+    nodes, order = _chain_tree(34)                             # 33 inner levels
+    rc, _, why = _validate(nodes, order, 34)
+    assert rc == L.PT_ERR_UNSUPPORTED and "deeper" in why
+    # the library's own builder stays inside the bound whatever the input (here: 5000 coincident triangles)
+    verts = np.zeros((3, 3), np.float32); verts[1, 0] = verts[2, 1] = 1.0
+    tris = np.tile(np.array([[0, 1, 2]], np.uint32), (5000, 1))
+    nodes, order, depth = pt.bvh_build(verts, tris, max_leaf=1)
+    assert depth <= 32 and _validate(nodes, order, 5000)[0] == L.PT_OK
+
+
+def test_validate_refuses_malformed_trees():
+    data = pt.scene_data("CornellBox")
+    nodes, order, _ = pt.bvh_build(data.verts, data.tris, max_leaf=2)
+    assert _validate(nodes, order, data.n_tris)[0] == L.PT_OK
+    bad = nodes.copy(); bad["child"][0, 0] = 10_000
+    assert _validate(bad, order, data.n_tris)[0] == L.PT_ERR_INVALID
+    bad = nodes.copy(); bad["child"][0, 1] = 0                 # cycle back to the root
+    assert _validate(bad, order, data.n_tris)[0] == L.PT_ERR_INVALID
+    assert _validate(nodes, np.zeros_like(order), data.n_tris)[0] == L.PT_ERR_INVALID      # not a permutation
+    assert _validate(nodes[:1], order, data.n_tris)[0] == L.PT_ERR_INVALID                 # leaves do not cover
