@@ -258,6 +258,23 @@ int pt_render(pt_scene* scene, const pt_render_params* params, double* accum_rgb
 int pt_render_device(pt_scene* scene, const pt_render_params* params, double* accum_rgb_dev,
                      void* stream);
 
+/* ---- No counterpart in the reference.  pt_render_device for callers that cannot allocate device
+ * memory: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same
+ * arguments, same result bit for bit; the whole workspace of the call (path queues, hit records,
+ * counters, per-sample radiance, frame jitters) is one fixed array of PT_NOALLOC_SCRATCH_BYTES that
+ * lives in the library's code object - every GPU the library runs on holds it from load until the
+ * process ends - so the call makes no hipMalloc / hipFree / event or stream creation.  Frames per
+ * batch are cut to what fits; PT_ERR_UNSUPPORTED, with the sizes in pt_last_error(), if a single
+ * frame of the tile does not fit: 655 360 tile pixels per call (e.g. 1920 x 340), 393 216 with
+ * PT_FLAG_NEE, 327 680 with PT_FLAG_PROPAGATE_DIFFS on a textured scene (262 144 with both).  No kernel timing on this
+ * path (pt_set_profiling level 1 is ignored; the counters of level 2 work).  Every call on a GPU
+ * shares that GPU's array: calls that overlap on one GPU - from two streams, two scenes or two host
+ * threads - race; order them on one stream, or with events.  The first call on a device looks the
+ * array's address up (no allocation, but make it outside graph capture). */
+#define PT_NOALLOC_SCRATCH_BYTES (128u << 20)
+int pt_render_device_noalloc(pt_scene* scene, const pt_render_params* params, double* accum_rgb_dev,
+                             void* stream);
+
 /* ---- main.rs:456-467 get_raw_pixels_u32 / mipmap.rs:21-23 f64_to_8bit_color:
  * rgb8[i] = clamp(accum[i] / iterations) * 255 + 0.5 truncated; no gamma. (host) */
 int pt_resolve_rgb8(const double* accum_rgb, size_t n_pixels, uint64_t iterations, uint8_t* rgb8);

@@ -930,6 +930,95 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
     return PT_OK;
 }
 
+}  // extern "C"
+
+// ---- pt_render_device_noalloc: the same render over a fixed workspace the library never allocates -----
+// `scratch` is the whole workspace of such a call (path queues, hit records, segment counters,
+// per-sample radiance, frame jitters), carved exactly like the hipMalloc'ed one.  Every GPU the
+// library runs on holds its own copy of the array, at its own address, from the moment the code
+// object is loaded until the process ends.  In host code the array's NAME is only a handle for
+// hipGetSymbolAddress: the device address it yields (once per device, with that device current) is
+// what the kernels, hipMemsetAsync and the carving below are given, never the name itself.
+static __device__ __align__(256) unsigned char scratch[PT_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+constexpr uint32_t kNoAllocJitterFrames = 1024;  // frames per batch of a no-alloc call at most (16 KiB of jitters)
+std::mutex g_scratch_mu;
+unsigned char* g_scratch_ptr[kMaxDevices];  // device address of `scratch` on device d (nullptr: not looked up yet)
+
+// device `dev` must be current
+int scratch_address(int dev, unsigned char** out) {
+    if (dev < 0 || dev >= kMaxDevices) { set_error("device %d: the static workspace supports devices 0..%d", dev, kMaxDevices - 1); return PT_ERR_UNSUPPORTED; }
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            set_error("hipGetSymbolAddress(scratch) on device %d failed: %s", dev, hipGetErrorString(e));
+            return PT_ERR_DEVICE;
+        }
+        g_scratch_ptr[dev] = (unsigned char*)p;
+    }
+    *out = g_scratch_ptr[dev];
+    return PT_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int pt_render_device_noalloc(pt_scene* s, const pt_render_params* P, double* accum_dev, void* stream) {
+    if (!s || !accum_dev) { set_error("null argument"); return PT_ERR_INVALID; }
+    int rc = check_params(P);
+    if (rc != PT_OK) return rc;
+    if (P->sample_count == 0) return PT_OK;
+    std::lock_guard<std::mutex> lk(s->mu);
+    DeviceGuard guard(s->device);
+    if (!guard.ok) { set_error("hipSetDevice(%d) failed", s->device); return PT_ERR_DEVICE; }
+    unsigned char* base = nullptr;
+    if ((rc = scratch_address(s->device, &base)) != PT_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+
+    const uint32_t npix = (P->x1 - P->x0) * (P->y1 - P->y0);
+    const bool nee = (P->flags & PT_FLAG_NEE) != 0 && s->dev.n_lights > 0;
+    const bool diffs = (P->flags & PT_FLAG_PROPAGATE_DIFFS) && (P->flags & PT_FLAG_USE_DIFFS) && s->n_texs > 0 &&
+                       P->max_bounces > 0;
+    // the frame jitters sit in front of the carved workspace
+    const size_t jitter_bytes = ((size_t)kNoAllocJitterFrames * 2 * sizeof(double) + 255) & ~(size_t)255;
+    const size_t room = (size_t)PT_NOALLOC_SCRATCH_BYTES - jitter_bytes;
+    auto needed = [&](uint32_t frames) {
+        size_t total = 0;
+        Workspace probe;
+        carve_workspace(probe, nullptr, frames * npix, frames * npix, 1, nee, diffs, total);
+        return total;
+    };
+    // frames per batch: what the caller asked for, what fits otherwise - one lane, one stream
+    uint32_t spp = P->spp_per_batch ? P->spp_per_batch : P->sample_count;
+    spp = std::min(std::min(spp, P->sample_count), kNoAllocJitterFrames);
+    spp = std::min<uint32_t>(spp, std::max<uint32_t>(1u, (1u << 27) / npix));
+    while (spp > 1 && needed(spp) > room) spp = (spp + 1) / 2;
+    const size_t total = needed(spp);
+    if (total > room) {
+        set_error("one frame of a %ux%u tile%s needs a %zu-byte workspace; the static one holds %zu bytes "
+                  "(PT_NOALLOC_SCRATCH_BYTES): render smaller tiles, or call pt_render_device",
+                  P->x1 - P->x0, P->y1 - P->y0, nee ? " with NEE" : "", total, room);
+        return PT_ERR_UNSUPPORTED;
+    }
+    Workspace w;  // pointers into `scratch` only: w.buf and w.jitter own nothing
+    size_t carved = 0;
+    carve_workspace(w, base + jitter_bytes, spp * npix, spp * npix, 1, nee, diffs, carved);
+    // What must start at zero is zeroed per batch on `st` (the segment counters, render_batches); the
+    // rest of the array keeps the previous call's bytes, which no kernel reads before writing: queue
+    // entries and hit records are only read below the counters of the same batch, and the bounce-0
+    // kernel stores every word of the radiance bitmap that the batch's accumulate reads.
+    s->timers_off = true;   // a HIP-event pair per launch would have to be created: no kernel timing on this path
+    rc = render_batches(s, P, accum_dev, st, w, (double*)base, spp, false, nee, diffs);
+    s->timers_off = false;
+    if (rc != PT_OK) return rc;
+    s->stats.samples += (uint64_t)npix * P->sample_count;
+    return PT_OK;
+}
+
 int pt_render(pt_scene* s, const pt_render_params* P, double* accum_rgb) {
     if (!s || !accum_rgb) { set_error("null argument"); return PT_ERR_INVALID; }
     int rc = check_params(P);

@@ -311,6 +311,13 @@ class Scene:
         p = cfg.params(sample_begin, sample_count, tile)
         L.check(L.lib.pt_render_device(self._h, C.byref(p), C.c_void_p(accum_ptr), C.c_void_p(stream)))
 
+    def render_device_noalloc(self, cfg: Config, accum_ptr: int, sample_begin: int, sample_count: int, tile=None,
+                              stream: int = 0) -> None:
+        """``render_device`` over the library's static workspace (pt_render_device_noalloc): no device
+        allocation, bounded tile size."""
+        p = cfg.params(sample_begin, sample_count, tile)
+        L.check(L.lib.pt_render_device_noalloc(self._h, C.byref(p), C.c_void_p(accum_ptr), C.c_void_p(stream)))
+
     def set_profiling(self, level: int) -> None:
         L.check(L.lib.pt_set_profiling(self._h, level))
 
