@@ -258,6 +258,25 @@ int pt_render(pt_scene* scene, const pt_render_params* params, double* accum_rgb
 int pt_render_device(pt_scene* scene, const pt_render_params* params, double* accum_rgb_dev,
                      void* stream);
 
+/* ---- main.rs:396-400, 434-467: the frame loop's running sum `pixels`, kept on the device.  The reference's
+ * window loop adds one frame per iteration and shows clamp(sum / iterations) each time; with pt_render
+ * that is a 50 MB upload and download of the f64 sums per frame at 1080p.  A pt_accum holds the sums in
+ * HBM next to the scene: pt_accum_render adds frames (params->width/height must be the handle's; it only
+ * enqueues, on the handle's own stream), pt_accum_resolve_* runs main.rs:456-467 on the device and
+ * brings back the 8-bit image alone through page-locked staging (rgb8: 3 bytes per pixel, the PPM
+ * writer's order; u32: 0x00RRGGBB as get_raw_pixels_u32 packs it for the window), pt_accum_download /
+ * pt_accum_upload move the f64 sums for checkpoints (upload NULL = clear).  pt_accum_device exposes the
+ * device pointer and stream for callers that mix in their own device work.  Destroy before the scene. */
+typedef struct pt_accum pt_accum;
+int pt_accum_create(pt_scene* scene, uint32_t width, uint32_t height, pt_accum** out);
+void pt_accum_destroy(pt_accum* acc);
+int pt_accum_render(pt_accum* acc, const pt_render_params* params);
+int pt_accum_resolve_rgb8(pt_accum* acc, uint64_t iterations, uint8_t* rgb8 /* [w*h*3] host */);
+int pt_accum_resolve_u32(pt_accum* acc, uint64_t iterations, uint32_t* packed /* [w*h] host */);
+int pt_accum_download(pt_accum* acc, double* accum_rgb /* [w*h*3] host */);
+int pt_accum_upload(pt_accum* acc, const double* accum_rgb /* [w*h*3] host, or NULL to clear */);
+int pt_accum_device(pt_accum* acc, double** sums_dev, void** stream);
+
 /* ---- No counterpart in the reference.  pt_render_device for callers that cannot allocate device
  * memory: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same
  * arguments, same result bit for bit; the whole workspace of the call (path queues, hit records,

@@ -106,6 +106,14 @@ PROTOTYPES = {
                                     _P(C.c_double)]),
     "pt_render": (C.c_int, [_vp, _P(pt_render_params), _P(C.c_double)]),
     "pt_render_device": (C.c_int, [_vp, _P(pt_render_params), _vp, _vp]),
+    "pt_accum_create": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _P(_vp)]),
+    "pt_accum_destroy": (None, [_vp]),
+    "pt_accum_render": (C.c_int, [_vp, _P(pt_render_params)]),
+    "pt_accum_resolve_rgb8": (C.c_int, [_vp, C.c_uint64, _P(C.c_uint8)]),
+    "pt_accum_resolve_u32": (C.c_int, [_vp, C.c_uint64, _P(C.c_uint32)]),
+    "pt_accum_download": (C.c_int, [_vp, _P(C.c_double)]),
+    "pt_accum_upload": (C.c_int, [_vp, _P(C.c_double)]),
+    "pt_accum_device": (C.c_int, [_vp, _P(_vp), _P(_vp)]),
     "pt_render_device_noalloc": (C.c_int, [_vp, _P(pt_render_params), _vp, _vp]),
     "pt_resolve_rgb8": (C.c_int, [_P(C.c_double), C.c_size_t, C.c_uint64, _P(C.c_uint8)]),
     "pt_write_ppm": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, _P(C.c_uint8)]),

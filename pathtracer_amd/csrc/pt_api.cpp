@@ -1040,6 +1040,120 @@ int pt_render(pt_scene* s, const pt_render_params* P, double* accum_rgb) {
     return PT_OK;
 }
 
+}  // extern "C"
+
+// ---- pt_accum: the frame loop's running sum (main.rs:396-400 `pixels`), resident on the device ---------
+struct pt_accum {
+    pt_scene* scene = nullptr;
+    uint32_t width = 0, height = 0;
+    DevBuf sums;           // width * height * 3 doubles
+    DevBuf resolved;       // width * height u32 (or 3 u8) of the last resolve
+    void* pinned = nullptr;  // page-locked staging for downloads / uploads (width * height * 3 doubles)
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    ~pt_accum() {
+        if (pinned) (void)hipHostFree(pinned);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace ptd {
+void launch_resolve(const double* accum, size_t n_pixels, double denom, uint8_t* rgb8, uint32_t* packed, hipStream_t st);
+}
+
+extern "C" {
+
+int pt_accum_create(pt_scene* s, uint32_t width, uint32_t height, pt_accum** out) {
+    if (!s || !out) { set_error("null argument"); return PT_ERR_INVALID; }
+    *out = nullptr;
+    if (width == 0 || height == 0 || (uint64_t)width * height >= (1ull << 32)) { set_error("bad image size %ux%u", width, height); return PT_ERR_INVALID; }
+    DeviceGuard guard(s->device);
+    if (!guard.ok) { set_error("hipSetDevice(%d) failed", s->device); return PT_ERR_DEVICE; }
+    std::unique_ptr<pt_accum> a(new (std::nothrow) pt_accum());
+    if (!a) { set_error("out of memory"); return PT_ERR_NOMEM; }
+    a->scene = s; a->width = width; a->height = height;
+    const size_t bytes = (size_t)width * height * 3 * sizeof(double);
+    if (a->sums.alloc(bytes) != hipSuccess || a->resolved.alloc((size_t)width * height * 4) != hipSuccess ||
+        hipHostMalloc(&a->pinned, bytes, hipHostMallocDefault) != hipSuccess) {
+        set_error("accumulation buffer of %ux%u: allocation failed", width, height);
+        return PT_ERR_NOMEM;
+    }
+    HIP_TRY(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
+    HIP_TRY(hipMemsetAsync(a->sums.p, 0, bytes, a->stream));
+    *out = a.release();
+    return PT_OK;
+}
+
+void pt_accum_destroy(pt_accum* a) {
+    if (!a) return;
+    DeviceGuard guard(a->scene->device);
+    if (a->stream) (void)hipStreamSynchronize(a->stream);
+    delete a;
+}
+
+int pt_accum_render(pt_accum* a, const pt_render_params* P) {
+    if (!a || !P) { set_error("null argument"); return PT_ERR_INVALID; }
+    if (P->width != a->width || P->height != a->height) {
+        set_error("params are for %ux%u, the accumulation buffer is %ux%u", P->width, P->height, a->width, a->height);
+        return PT_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(a->mu);
+    return pt_render_device(a->scene, P, a->sums.as<double>(), a->stream);
+}
+
+static int accum_resolve(pt_accum* a, uint64_t iterations, uint8_t* rgb8, uint32_t* packed) {
+    if (!a || (!rgb8 && !packed) || iterations == 0) { set_error("bad argument"); return PT_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(a->mu);
+    DeviceGuard guard(a->scene->device);
+    if (!guard.ok) { set_error("hipSetDevice(%d) failed", a->scene->device); return PT_ERR_DEVICE; }
+    const size_t npix = (size_t)a->width * a->height, bytes = rgb8 ? npix * 3 : npix * 4;
+    ptd::launch_resolve(a->sums.as<double>(), npix, 1. / (double)iterations, rgb8 ? a->resolved.as<uint8_t>() : nullptr,
+                        packed ? a->resolved.as<uint32_t>() : nullptr, a->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(a->pinned, a->resolved.p, bytes, hipMemcpyDeviceToHost, a->stream));
+    HIP_TRY(hipStreamSynchronize(a->stream));
+    std::memcpy(rgb8 ? (void*)rgb8 : (void*)packed, a->pinned, bytes);
+    return PT_OK;
+}
+int pt_accum_resolve_rgb8(pt_accum* a, uint64_t iterations, uint8_t* rgb8) { return accum_resolve(a, iterations, rgb8, nullptr); }
+int pt_accum_resolve_u32(pt_accum* a, uint64_t iterations, uint32_t* packed) { return accum_resolve(a, iterations, nullptr, packed); }
+
+int pt_accum_download(pt_accum* a, double* accum_rgb) {
+    if (!a || !accum_rgb) { set_error("null argument"); return PT_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(a->mu);
+    DeviceGuard guard(a->scene->device);
+    if (!guard.ok) { set_error("hipSetDevice(%d) failed", a->scene->device); return PT_ERR_DEVICE; }
+    const size_t bytes = (size_t)a->width * a->height * 3 * sizeof(double);
+    HIP_TRY(hipMemcpyAsync(a->pinned, a->sums.p, bytes, hipMemcpyDeviceToHost, a->stream));
+    HIP_TRY(hipStreamSynchronize(a->stream));
+    std::memcpy(accum_rgb, a->pinned, bytes);
+    return PT_OK;
+}
+
+int pt_accum_upload(pt_accum* a, const double* accum_rgb) {
+    if (!a) { set_error("null argument"); return PT_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(a->mu);
+    DeviceGuard guard(a->scene->device);
+    if (!guard.ok) { set_error("hipSetDevice(%d) failed", a->scene->device); return PT_ERR_DEVICE; }
+    const size_t bytes = (size_t)a->width * a->height * 3 * sizeof(double);
+    if (!accum_rgb) {  // start over
+        HIP_TRY(hipMemsetAsync(a->sums.p, 0, bytes, a->stream));
+        return PT_OK;
+    }
+    HIP_TRY(hipStreamSynchronize(a->stream));  // the staging buffer may still feed an earlier copy
+    std::memcpy(a->pinned, accum_rgb, bytes);
+    HIP_TRY(hipMemcpyAsync(a->sums.p, a->pinned, bytes, hipMemcpyHostToDevice, a->stream));
+    HIP_TRY(hipStreamSynchronize(a->stream));
+    return PT_OK;
+}
+
+int pt_accum_device(pt_accum* a, double** sums_dev, void** stream) {
+    if (!a) { set_error("null argument"); return PT_ERR_INVALID; }
+    if (sums_dev) *sums_dev = a->sums.as<double>();
+    if (stream) *stream = (void*)a->stream;
+    return PT_OK;
+}
+
 int pt_trace_closest(pt_scene* s, const pt_ray* rays, size_t n, uint32_t* tri_id, double* t) {
     if (!s || (n && (!rays || !tri_id || !t))) { set_error("null argument"); return PT_ERR_INVALID; }
     std::lock_guard<std::mutex> lk(s->mu);

@@ -72,6 +72,26 @@ __global__ void k_texture_lookup(Scene sc, uint32_t tex, const double* __restric
     rgb[3 * i] = c.x; rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z;
 }
 
+// main.rs:456-467 get_raw_pixels_u32 / mipmap.rs:21-23 f64_to_8bit_color on the device-resident sums: the
+// arithmetic of the host's pt_resolve_rgb8, value for value (clamp(sum / iterations) * 255 + 0.5,
+// truncated; `as u8` saturates and maps NaN to 0).  One lane per pixel; rgb8 (3 bytes per pixel, the
+// PPM writer's order) or packed 0x00RRGGBB words (the window buffer), whichever pointer is given.
+__global__ __launch_bounds__(kBlock) void k_resolve(const double* __restrict__ accum, size_t n_pixels, double denom,
+                                                    uint8_t* __restrict__ rgb8, uint32_t* __restrict__ packed) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_pixels) return;
+    uint32_t q[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double x = accum[i * 3 + c] * denom;
+        x = x < 0. ? 0. : (x > 1. ? 1. : x);
+        const double v = x * 255. + 0.5;
+        q[c] = !(v > 0.) ? 0u : (v >= 255. ? 255u : (uint32_t)v);
+    }
+    if (rgb8) { rgb8[i * 3] = (uint8_t)q[0]; rgb8[i * 3 + 1] = (uint8_t)q[1]; rgb8[i * 3 + 2] = (uint8_t)q[2]; }
+    if (packed) packed[i] = (q[0] << 16) | (q[1] << 8) | q[2];
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 static inline uint32_t blocks_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
@@ -80,6 +100,10 @@ void launch_jitter(uint64_t seed, uint64_t sample_begin, uint32_t n, double psx,
                    hipStream_t st) {
     if (!n) return;
     hipLaunchKernelGGL(k_jitter, dim3(blocks_for(n)), dim3(kBlock), 0, st, seed, sample_begin, n, psx, psy, out);
+}
+void launch_resolve(const double* accum, size_t n_pixels, double denom, uint8_t* rgb8, uint32_t* packed, hipStream_t st) {
+    if (!n_pixels) return;
+    hipLaunchKernelGGL(k_resolve, dim3((uint32_t)((n_pixels + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, accum, n_pixels, denom, rgb8, packed);
 }
 void launch_generate_rays(const Scene& sc, const Frame& fr, double* rays_out, hipStream_t st) {
     if (!fr.n_tile_pixels) return;

@@ -341,6 +341,65 @@ class Scene:
         return nodes, order, depth.value
 
 
+class Accum:
+    """main.rs:396-400 ``pixels`` + ``iterations``: the running sum of a progressive render, resident on the
+    scene's device (pt_accum).  ``render`` adds frames without a host round trip; ``resolve_rgb8`` /
+    ``resolve_u32`` bring back only the 8-bit image (main.rs:456-467), ``download`` the f64 sums."""
+
+    def __init__(self, scene: "Scene", cfg: Config):
+        self.scene, self.cfg = scene, cfg
+        self.iterations = 0
+        self._h = C.c_void_p()
+        L.check(L.lib.pt_accum_create(scene._h, cfg.w, cfg.h, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            L.lib.pt_accum_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, sample_count: int = 1, tile=None) -> None:
+        """The next ``sample_count`` iterations of the frame loop (main.rs:400-436)."""
+        p = self.cfg.params(self.iterations, sample_count, tile)
+        L.check(L.lib.pt_accum_render(self._h, C.byref(p)))
+        self.iterations += sample_count
+
+    def resolve_rgb8(self) -> np.ndarray:
+        out = np.empty((self.cfg.h, self.cfg.w, 3), np.uint8)
+        L.check(L.lib.pt_accum_resolve_rgb8(self._h, max(1, self.iterations), _ptr(out, C.c_uint8)))
+        return out
+
+    def resolve_u32(self) -> np.ndarray:
+        out = np.empty((self.cfg.h, self.cfg.w), np.uint32)
+        L.check(L.lib.pt_accum_resolve_u32(self._h, max(1, self.iterations), _ptr(out, C.c_uint32)))
+        return out
+
+    def download(self) -> np.ndarray:
+        out = np.empty((self.cfg.h, self.cfg.w, 3), np.float64)
+        L.check(L.lib.pt_accum_download(self._h, _ptr(out, C.c_double)))
+        return out
+
+    def upload(self, accum: Optional[np.ndarray], iterations: int = 0) -> None:
+        if accum is None:
+            L.check(L.lib.pt_accum_upload(self._h, None))
+        else:
+            accum = np.ascontiguousarray(accum, dtype=np.float64)
+            assert accum.size == self.cfg.w * self.cfg.h * 3
+            L.check(L.lib.pt_accum_upload(self._h, _ptr(accum, C.c_double)))
+        self.iterations = iterations
+
+    def device(self):
+        """(device pointer of the sums, hipStream_t of the handle) as integers."""
+        p, st = C.c_void_p(), C.c_void_p()
+        L.check(L.lib.pt_accum_device(self._h, C.byref(p), C.byref(st)))
+        return p.value, st.value or 0
+
+
 # ---- scene presets (cameras: SURVEY.md F6) ------------------------------------------------------
 CAMERAS = {
     # scene.rs:184-186

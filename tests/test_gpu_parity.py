@@ -282,6 +282,46 @@ def test_two_lane_pipeline_is_bitwise_invariant(gpu, monkeypatch, nee):
     assert (np.abs(img - ref) > 1e-9 * np.maximum(1.0, np.abs(ref))).mean() < 1e-3
 
 
+def test_accum_handle_frame_loop_equals_one_render(scenes):
+    # the reference's window loop (main.rs:400-452): one frame per iteration, the image shown after each.
+    # Through the device-resident handle N single-frame calls leave the very sums of one N-frame pt_render,
+    # and the device-side resolve equals the host's (main.rs:456-467) byte for byte, packed words included.
+    data, scene, oracle = scenes["CornellBox"]
+    cfg = pt.Config(width=320, height=180, bounces=2, seed=17)
+    acc = pt.Accum(scene, cfg)
+    n = 7
+    for it in range(1, n + 1):
+        acc.render(1)
+        if it in (1, 4):
+            shown = acc.resolve_rgb8()
+            assert shown.tobytes() == pt.resolve_rgb8(scene.render(cfg, sample_begin=0, sample_count=it), it).tobytes()
+    whole = scene.render(cfg, sample_begin=0, sample_count=n)
+    sums = acc.download()
+    assert sums.tobytes() == whole.tobytes()
+    rgb = acc.resolve_rgb8()
+    assert rgb.tobytes() == pt.resolve_rgb8(whole, n).tobytes() and rgb.any()
+    u32 = acc.resolve_u32()
+    r, g, b = (rgb[..., k].astype(np.uint32) for k in range(3))
+    assert np.array_equal(u32, (r << 16) | (g << 8) | b)           # main.rs:463-465
+    # resume from a checkpoint of the sums: upload, go on, same bits as the uninterrupted loop
+    other = pt.Accum(scene, cfg)
+    other.upload(scene.render(cfg, sample_begin=0, sample_count=3), iterations=3)
+    other.render(4)
+    assert other.download().tobytes() == whole.tobytes()
+    other.upload(None)
+    assert not other.download().any()
+    with pytest.raises(pt.PtError):                                # a handle renders its own image size only
+        L = pt.Config(width=64, height=64)
+        import ctypes as C
+        from pathtracer_amd import _lib
+        p = L.params(0, 1)
+        _lib.check(_lib.lib.pt_accum_render(other._h, C.byref(p)))
+    # NaN / negative / > 1 sums resolve as the host does (`as u8` saturates, NaN -> 0)
+    odd = np.zeros((cfg.h, cfg.w, 3)); odd[0, 0] = [np.nan, -3.0, 9.0]; odd[0, 1] = [0.5, 1.0, 0.999999]
+    other.upload(odd, iterations=1)
+    assert other.resolve_rgb8().tobytes() == pt.resolve_rgb8(odd, 1).tobytes()
+
+
 def test_two_streams_share_one_scene(gpu):
     # pt_render_device is asynchronous on the caller's stream, and every call on a scene uses the scene's
     # one workspace: calls issued alternately on two streams must still not overlap on the device (each
