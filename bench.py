@@ -2,187 +2,132 @@
 """bench.py — throughput of the radiance inner loop on MI355X (BASELINE.json metric: Msamples/s).
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): models/CornellBox.obj, 1920x1080,
-bounces = 2, f64.  A "step" is one wavefront pass of the hot path over `--spp` frames of the whole
-image (generate -> [extend -> shade] x 3 -> accumulate).  With N > 1 the work is split by
-sample ranges: every rank renders the full image for its own, disjoint frame indices (fixed
-per-GPU work => weak scaling) and the f64 accumulation buffers are summed onto rank 0 with one
-RCCL reduce at the end of the timed region (partitioning 2).  `--partition tiles` is
-the other form (§8e partitioning 1): row bands of the one image, every rank the same frames, one
-RCCL all-gather at the end (fixed total work => strong scaling).  The scene and the accumulation
-buffer are resident in HBM before the timed region starts.
+Headline workload (BASELINE.json configs[1]): models/CornellBox.obj, 1920x1080,
+1024 spp, bounces = 2, f64.  A "step" is one pass of the hot path over the config as named: all 1024
+frames of the image (generate -> [extend -> shade] x 3 -> accumulate), rendered as 16 batches of 64
+frames.  The scene and the accumulation buffer are resident in HBM before the timed region starts.
 
-Prints ONE JSON line on rank 0; see DESIGN.md "Measurement" for the roofline/cpu_baseline fields.
+With N > 1 and no launcher in the environment, bench.py starts its own N ranks (a child
+`python -m torch.distributed.run`, before this process touches the GPU).  The work is cut by
+pathtracer_amd/dist.py: `--partition samples` (default) gives every rank the whole image for its own
+1024 frames per step (fixed per-GPU work => weak scaling) and hands the partial sums to rank 0, added
+in rank order, once, at the end of the timed region; `--partition tiles` gives every rank the row groups
+g % N == rank of the one image (fixed total work => strong scaling) and gathers the rows to rank 0.
+
+At N = 1 the other BASELINE configs (glossy_planes 1080p, textured Test.obj 4K, the 10 M-triangle
+heightfield 4K) are timed for a few steps each after the headline and reported under "configs", each
+with its own roofline; `--configs none` skips them.
+
+Prints ONE JSON line on rank 0; see DESIGN.md "Measurement" for the roofline / cpu_baseline fields.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MAX_CLOCK_HZ = 2.4e9       # MI355X_MICROARCH.md: max clock
+N_SIMD = 256 * 4           # 256 CUs x 4 SIMDs
+FP64_VALU_PEAK_TFLOPS = 78.6   # spec vector FP64 (FMA = 2 flops); the reference's arithmetic has no FMA: half of it
+
+# The BASELINE.json configs that run on a GPU.  `spp` = frames per step (the config as named), `batch` =
+# frames in flight per wavefront pass.
+WORKLOADS = {
+    "CornellBox": dict(scene="CornellBox", width=1920, height=1080, spp=1024, batch=64, label="BASELINE.json configs[1]"),
+    "glossy_planes": dict(scene="glossy_planes", width=1920, height=1080, spp=256, batch=64, label="BASELINE.json configs[2]"),
+    "Test_textured": dict(scene="Test", textures=True, width=3840, height=2160, spp=64, batch=16, label="BASELINE.json configs[3]"),
+    "heightfield": dict(scene="heightfield", width=3840, height=2160, spp=4096, batch=16, label="BASELINE.json configs[4]"),
+}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--spp", type=int, default=64, help="frames per step")
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--scene", default="CornellBox", help="models/<scene>.obj, or 'heightfield' (SURVEY config 5)")
-    ap.add_argument("--cells", type=int, default=2236, help="heightfield resolution (2236 -> 9,999,392 triangles)")
-    ap.add_argument("--bounces", type=int, default=2)
-    ap.add_argument("--partition", choices=("samples", "tiles"), default="samples",
-                    help="N > 1: 'samples' = every rank renders the whole image for its own frames, one RCCL reduce "
-                         "(weak scaling, the measured default); 'tiles' = row bands of the one image, one RCCL "
-                         "all-gather (SURVEY.md §8e partitioning 1, strong scaling)")
-    ap.add_argument("--nee", action="store_true", help="next-event estimation (shadow rays) on")
-    ap.add_argument("--textures", action="store_true", help="load map_Kd textures (BASELINE configs[3]: --scene Test)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
-    args = ap.parse_args()
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
-    import pathtracer_amd as pt  # loads the HIP library (and pins the process to one HIP runtime)
-    import torch
-    import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # Rehearsal knobs for a 1-GPU box (never set by the driver): all ranks on one device, gloo
-    # instead of RCCL (RCCL refuses two ranks on one GPU).  The measured configuration is nccl.
-    backend = os.environ.get("PT_BENCH_BACKEND", "nccl")
-    if "PT_BENCH_DEVICE" in os.environ:
-        local_rank = int(os.environ["PT_BENCH_DEVICE"])
-    if world > 1:
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+def pmc_key(wl, bounces, nee):
+    return (f"{wl['scene']}{'_tex' if wl.get('textures') else ''}{'_nee' if nee else ''}_{wl['width']}x{wl['height']}"
+            f"_batch{wl['batch']}_b{bounces}")
+
+
+def load_pmc():
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+class Workload:
+    """One scene + config on this rank's GPU, with the step / instrumentation / roofline logic."""
+
+    def __init__(self, pt, torch, wl, args, dev, local_rank, part=None):
+        self.pt, self.torch, self.wl, self.args, self.dev, self.part = pt, torch, wl, args, dev, part
+        if wl["scene"] == "heightfield":
+            from pathtracer_amd.synthetic import heightfield_box
+            self.data = heightfield_box(args.cells)
         else:
-            dist.init_process_group(backend=backend)
-    n_gpus = world
-    if args.gpus != n_gpus and rank == 0:
-        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run for N>1",
-              file=sys.stderr)
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+            self.data = pt.scene_data(wl["scene"], textures=bool(wl.get("textures")))
+        self.scene = pt.Scene(self.data, device=local_rank)
+        self.w, self.h, self.spp, self.batch = wl["width"], wl["height"], wl["spp"], wl["batch"]
+        self.cfg = pt.Config(width=self.w, height=self.h, bounces=args.bounces, seed=1, spp_per_batch=self.batch, nee=args.nee)
+        self.accum = torch.zeros((self.h, self.w, 3), dtype=torch.float64, device=dev)
+        self.stream = torch.cuda.current_stream(dev).cuda_stream
+        self.world = part.world if part is not None else 1
+        self.rank = part.rank if part is not None else 0
 
-    if args.scene == "heightfield":
-        from pathtracer_amd.synthetic import heightfield_box
-        data = heightfield_box(args.cells)
-    else:
-        data = pt.scene_data(args.scene, textures=args.textures)
-    scene = pt.Scene(data, device=local_rank)
-    cfg = pt.Config(width=args.width, height=args.height, bounces=args.bounces, seed=1, spp_per_batch=args.spp,
-                    nee=args.nee)
-    accum = torch.zeros((args.height, args.width, 3), dtype=torch.float64, device=dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    npix = args.width * args.height
+    def render_fn(self, accum, tile, s0, n, rows):
+        self.scene.render_device(self.cfg, accum.data_ptr(), s0, n, tile=tile, stream=self.stream, rows=rows)
 
-    tiles = world > 1 and args.partition == "tiles"
-    if tiles and args.height % world:
-        raise SystemExit(f"--partition tiles needs --height divisible by the number of ranks ({args.height} % {world})")
-    band = args.height // world if tiles else args.height
-    y0 = rank * band if tiles else 0
+    def step(self, i):
+        """Step i: frames [i * spp * world', +spp * world') of the job, this rank's share of them."""
+        if self.part is None:
+            self.render_fn(self.accum, None, i * self.spp, self.spp, None)
+        elif self.part.mode == "samples":   # the job's step = world x spp frames, spp of them here
+            self.part.render(self.render_fn, self.accum, i * self.spp * self.world, self.spp * self.world)
+        else:                                # every rank the same spp frames, its own rows
+            self.part.render(self.render_fn, self.accum, i * self.spp, self.spp)
 
-    def step(i):
-        if tiles:   # every rank the same frames, its own rows
-            scene.render_device(cfg, accum.data_ptr(), i * args.spp, args.spp, tile=(0, y0, args.width, y0 + band),
-                                stream=stream)
-        else:       # frames [base, base + spp): disjoint across ranks and steps
-            scene.render_device(cfg, accum.data_ptr(), (i * world + rank) * args.spp, args.spp, stream=stream)
+    def pixels(self):
+        return self.part.pixels() if (self.part is not None and self.part.mode != "samples") else self.w * self.h
 
-    def exchange():   # the job's one exchange, RCCL over xGMI (gloo through the host in rehearsals)
-        if tiles:
-            mine = accum[y0:y0 + band].contiguous()
-            if backend == "nccl":
-                dist.all_gather_into_tensor(accum.view(-1), mine.view(-1))
-            else:
-                parts = [torch.empty(mine.shape, dtype=mine.dtype) for _ in range(world)]
-                dist.all_gather(parts, mine.cpu())
-                accum.copy_(torch.cat(parts, dim=0))
-        elif backend == "nccl":
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
-        else:
-            host = accum.cpu()
-            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
-            accum.copy_(host)
+    # ---- V, T and lit samples per ray from one instrumented batch (profiling level 2) -------------------
+    def instrument(self, first_frame):
+        pt, torch, scene = self.pt, self.torch, self.scene
+        out = {}
+        for label, bounces in (("all", self.args.bounces), ("primary", 0)):
+            scene.reset_stats()
+            scene.set_profiling(2)
+            cfg = pt.Config(width=self.w, height=self.h, bounces=bounces, seed=1, spp_per_batch=self.batch, nee=self.args.nee)
+            scratch = torch.zeros_like(self.accum)
+            scene.render_device(cfg, scratch.data_ptr(), first_frame, self.batch, stream=self.stream)
+            torch.cuda.synchronize(self.dev)
+            out[label] = scene.stats()
+            scene.set_profiling(0)
+            del scratch
+        return out["all"], out["primary"]
 
-    def fence():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-
-    for i in range(args.warmup):
-        step(i)
-    if world > 1 and backend == "nccl":
-        # first use of a collective builds channels and loads its kernel: not part of a step
-        if tiles:
-            dist.all_gather_into_tensor(torch.zeros_like(accum).view(-1), torch.zeros_like(accum[y0:y0 + band]).view(-1))
-        else:
-            dist.reduce(torch.zeros_like(accum), dst=0, op=dist.ReduceOp.SUM)
-    fence()
-    scene.reset_stats()
-    scene.set_profiling(1)  # HIP events around every kernel launch of the timed region
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    if world > 1:
-        exchange()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    st = scene.stats()
-    scene.set_profiling(0)
-
-    samples_per_rank = (band * args.width) * args.spp * args.steps
-    rays_t = torch.tensor([float(st["rays"])], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(rays_t, op=dist.ReduceOp.SUM)
-    total_rays = float(rays_t.item())
-    total_samples = samples_per_rank * world
-    value = total_samples / dt / 1e6
-
-    out = None
-    if rank == 0:
-        # ---- roofline of the dominant kernel (rank 0's launches, HIP-event durations) ----------
+    # ---- roofline of the dominant kernel -----------------------------------------------------------------
+    def roofline(self, st, samples_per_rank, first_free_frame):
+        args, data, scene = self.args, self.data, self.scene
+        npix = self.w * self.h
         kern = st["kernel"]
         dom = max(kern, key=lambda k: kern[k]["ms"])
         total_kernel_ms = sum(k["ms"] for k in kern.values())
-        # V (child boxes slab-tested) and T (triangles tested) per ray: one instrumented step
-        scene.reset_stats()
-        scene.set_profiling(2)
-        step(args.warmup + args.steps)
-        torch.cuda.synchronize(dev)
-        st2 = scene.stats()
-        scene.set_profiling(0)
+        st2, st0 = self.instrument(first_free_frame)
         rays2 = max(1, st2["rays"])
-        V = st2["nodes_visited"] / rays2
-        T = st2["tris_tested"] / rays2
-        # the same for the primary rays alone (the same frames with bounces = 0)
-        scene.reset_stats()
-        scene.set_profiling(2)
-        cfg0 = pt.Config(width=args.width, height=args.height, bounces=0, seed=1, spp_per_batch=args.spp, nee=args.nee)
-        scratch = torch.zeros_like(accum)
-        scene.render_device(cfg0, scratch.data_ptr(), ((args.warmup + args.steps) * world + rank) * args.spp, args.spp,
-                            stream=stream)
-        torch.cuda.synchronize(dev)
-        st0 = scene.stats()
-        scene.set_profiling(0)
-        del scratch
-        V0 = st0["nodes_visited"] / max(1, st0["rays"])
-        T0 = st0["tris_tested"] / max(1, st0["rays"])
+        V, T = st2["nodes_visited"] / rays2, st2["tris_tested"] / rays2
+        V0, T0 = st0["nodes_visited"] / max(1, st0["rays"]), st0["tris_tested"] / max(1, st0["rays"])
         # Algorithmic bytes (DESIGN.md "Measurement").  SURVEY.md §8d prices a ray at
         # B_ray = 32 V + 36 T + 128: V child boxes (32 B each), T triangles (36 B) and one path
         # record written by the producer and read by the consumer.  Per kernel, with this build's
@@ -194,18 +139,15 @@ def main():
         #               per sample 1 bit, per lit sample 24 written
         #   accumulate  per sample 1 bit, per lit sample 24 read, per pixel and launch 48 (accum
         #               read-modify-write)
-        # (the radiance of a sample is stored only if it gathered any: DESIGN.md "sparse radiance";
-        # `lit` is counted by the instrumented step)
-        # The scene terms 32 V + 36 T are added to the traversing kernel only when the scene does
-        # not fit one XCD's L2 (config 5); for a cache-resident scene they are reported as L2-served.
+        # The scene terms 32 V + 36 T are HBM bytes of the traversing kernel only when the scene does
+        # not fit one XCD's L2 (config 5); for a cache-resident scene they are reported as L2/LDS-served.
         scene_bytes = data.n_tris * 48 + len(scene.bvh()[0]) * 64
         resident = scene_bytes < (4 << 20)  # one XCD's L2
         scene_ray = 32.0 * V + 36.0 * T
         rec, hit = 76.0, 12.0
         P = float(samples_per_rank)                 # primary rays of the timed region
         lit = P * st2["lit_samples"] / max(1, st2["samples"])   # samples that gathered radiance
-        # primary rays actually traced (those through pixels outside the scene's screen bounds are not)
-        P_traced = P * st0["rays"] / max(1, st0["samples"])
+        P_traced = P * st0["rays"] / max(1, st0["samples"])     # primary rays actually traced (screen bounds)
         S = max(0.0, float(st["rays"]) - P_traced)  # secondary rays == records written
         scene_all = float(st["rays"]) * scene_ray
         per_kind = {
@@ -216,13 +158,11 @@ def main():
             "shadow": float(st["shadow_rays"]) * (56.0 + 24.0 + 4.0),
             "generate": 0.0,
         }
-        # which kernel walked the tree for which rays: the fused path kernel every bounce of a shallow
-        # tree, or only the primary bounce of a deep one (the extend kernel then has the secondary rays)
         if kern["path"]["launches"] and kern["extend"]["launches"]:
-            scene_primary = P_traced * (32.0 * V0 + 36.0 * T0)
-            scene_of = {"path": scene_primary, "extend": scene_all - scene_primary}
             # deep tree: path = primary bounce only (writes the records of the secondary rays), extend and
             # shade = the secondary rays (records written by shade: the few survivors of the cull, ignored)
+            scene_primary = P_traced * (32.0 * V0 + 36.0 * T0)
+            scene_of = {"path": scene_primary, "extend": scene_all - scene_primary}
             per_kind["path"] = S * rec + P / 8.0 + lit * 24.0
             per_kind["extend"] = S * (48.0 + hit)
             per_kind["shade"] = S * (hit + rec) + lit * 24.0
@@ -238,24 +178,42 @@ def main():
         gbs = lambda b, ms: b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         achieved = gbs(bytes_per_launch, avg_ms)
         whole = sum(per_kind[k] for k in kern if kern[k]["launches"]) + (0.0 if resident else scene_all)
-        # HBM traffic per launch of the dominant kernel from the rocprofv3 PMC passes of this same
-        # command (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE; profiles/traffic.json, scripts/pmc_traffic.py)
-        traffic, pmc = None, {}
-        try:
-            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                tj = json.load(f)
-            key = f"{args.scene}_{args.width}x{args.height}_spp{args.spp}_b{args.bounces}"
-            pmc = tj.get(key, {}).get(dom, {})
-            traffic = pmc.get("traffic_bytes_per_launch")
-        except (OSError, ValueError):
-            pass
-        roofline = {
-            "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-            # from the committed rocprofv3 PMC passes of this command (profiles/traffic.json), not live:
-            "pmc": {k: pmc.get(k) for k in ("valu_busy", "lane_utilisation", "waves_per_simd", "l2_hit")} if pmc else None,
-            "avg_launch_ms": round(avg_ms, 4), "launches": launches,
+        # rocprofv3 PMC passes of this same workload, committed under profiles/ (scripts/pmc_collect.sh ->
+        # scripts/pmc_digest.py -> profiles/pmc.json): per launch of each kernel kind, HBM traffic
+        # ((FETCH_SIZE x 2 on gfx950) + WRITE_SIZE), VALU busy cycles, VALU instructions, lane cycles
+        pmc = load_pmc().get(pmc_key(self.wl, args.bounces, args.nee), {}).get(dom, {})
+        hbm = {
+            "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc.get("traffic_bytes_per_launch"),
             "algorithmic_bytes_per_launch": round(bytes_per_launch),
+        }
+        valu = None
+        if pmc.get("valu_busy_cycles_per_launch"):
+            # VALU issue: SIMD-cycles in which a vector instruction issues (SQ_ACTIVE_INST_VALU x 4, a count
+            # fixed by the workload: the RNG is counter-based) over the live launch duration, against
+            # 1024 SIMDs x the 2.4 GHz maximum clock.  lane_utilisation = active lanes per issued
+            # instruction / 64 (SQ_THREAD_CYCLES_VALU); useful = the two multiplied.
+            cyc = pmc["valu_busy_cycles_per_launch"]
+            ach = cyc / (avg_ms * 1e-3) / 1e9
+            peak = N_SIMD * MAX_CLOCK_HZ / 1e9
+            lane = pmc.get("lane_utilisation")
+            flops = pmc.get("fp64_flops_per_launch")  # wave-level F64 add/mul/fma(x2)/trans instructions x active lanes
+            valu = {
+                "bound": "valu-issue", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G SIMD-cycles/s",
+                "frac": round(ach / peak, 4), "traffic": pmc.get("traffic_bytes_per_launch"),
+                "valu_busy_at_effective_clock": pmc.get("valu_busy"), "effective_clock_ghz": pmc.get("clock_ghz"),
+                "lane_utilisation": lane, "useful_lane_frac": round(ach / peak * lane, 4) if lane else None,
+                "valu_insts_per_launch": pmc.get("valu_insts_per_launch"),
+                "fp64_tflops": round(flops / (avg_ms * 1e-3) / 1e12, 2) if flops else None,
+                "fp64_peak_tflops_no_fma": FP64_VALU_PEAK_TFLOPS / 2,
+                "waves_per_simd": pmc.get("waves_per_simd"),
+            }
+        # the bound: a scene that lives in cache / LDS is bound by vector issue, the 10 M-triangle scene by HBM gathers
+        main = dict(valu if (resident and valu) else hbm)
+        main.update({
+            "kernel": dom, "avg_launch_ms": round(avg_ms, 4), "launches": launches,
+            "hbm": hbm if (resident and valu) else None, "valu": valu if not resident else None,
+            "pmc": {k: pmc.get(k) for k in ("valu_busy", "lane_utilisation", "waves_per_simd", "l2_hit", "clock_ghz")} if pmc else None,
             "scene_cache_resident": resident, "scene_bytes": scene_bytes,
             "l2_served_GBs": round(gbs(l2_bytes / launches, avg_ms), 2),
             "nodes_per_ray": round(V, 3), "tris_per_ray": round(T, 3),
@@ -268,17 +226,138 @@ def main():
             "kernel_GBs": {k: round(gbs(per_kind[k] + (0.0 if resident else scene_of.get(k, 0.0)), v["ms"]), 1)
                            for k, v in kern.items() if v["launches"]},
             "whole_path_GBs": round(gbs(whole, total_kernel_ms), 2),
-        }
+        })
+        return main
+
+    def describe(self):
+        wl, args = self.wl, self.args
+        name = wl["scene"] + ("" if wl["scene"] == "heightfield" else ".obj")
+        return (f"{name} {self.w}x{self.h} bounces={args.bounces}{', NEE' if args.nee else ''}"
+                f"{', textures' if wl.get('textures') else ''}, {self.spp} spp per step per GPU in batches of {self.batch}"
+                f" ({wl['label']})")
+
+
+def timed_run(torch, dist, wk, steps, warmup, world, backend, exchange=None):
+    """W untimed + K timed steps bracketed by barrier + synchronize; returns (seconds [max over ranks], stats)."""
+    dev = wk.dev
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for i in range(warmup):
+        wk.step(i)
+    fence()
+    wk.scene.reset_stats()
+    wk.scene.set_profiling(1)  # HIP events around every kernel launch of the timed region, on the launch stream
+    fence()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        wk.step(warmup + i)
+    if exchange is not None:
+        exchange()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    st = wk.scene.stats()
+    wk.scene.set_profiling(0)
+    return dt, st
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="CornellBox", choices=sorted(WORKLOADS), help="the headline workload")
+    ap.add_argument("--spp", type=int, default=0, help="frames per step (default: the config as named)")
+    ap.add_argument("--batch", type=int, default=0, help="frames in flight per wavefront pass (default per workload)")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--cells", type=int, default=2236, help="heightfield resolution (2236 -> 9,999,392 triangles)")
+    ap.add_argument("--bounces", type=int, default=2)
+    ap.add_argument("--partition", choices=("samples", "tiles", "bands"), default="samples",
+                    help="N > 1: 'samples' = every rank the whole image for its own frames, partial sums added on "
+                         "rank 0 in rank order (weak scaling, the measured default); 'tiles' = interleaved groups of 8 "
+                         "rows of the one image, one gather (SURVEY.md §8e.1, strong scaling); 'bands' = contiguous bands")
+    ap.add_argument("--nee", action="store_true", help="next-event estimation (shadow rays) on")
+    ap.add_argument("--configs", choices=("all", "none"), default="all",
+                    help="N = 1: also time the other BASELINE configs for a few steps each")
+    ap.add_argument("--config-steps", type=int, default=2)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
+    args = ap.parse_args()
+
+    # ---- N > 1 without a launcher: start the ranks ourselves, before anything here touches the GPU ------
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+    import pathtracer_amd as pt  # loads the HIP library (and pins the process to one HIP runtime)
+    import torch
+    import torch.distributed as dist
+    from pathtracer_amd.dist import Partition
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal knobs for a 1-GPU box (never set by the driver): all ranks on one device, gloo
+    # instead of RCCL (RCCL refuses two ranks on one GPU).  The measured configuration is nccl.
+    backend = os.environ.get("PT_BENCH_BACKEND", "nccl")
+    if "PT_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["PT_BENCH_DEVICE"])
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
+    if args.gpus != world and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: measuring {world} rank(s)", file=sys.stderr)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    wl = dict(WORKLOADS[args.workload])
+    for k in ("spp", "batch", "width", "height"):
+        if getattr(args, k):
+            wl[k] = getattr(args, k)
+    wl["batch"] = min(wl["batch"], wl["spp"])
+    part = Partition(args.partition, wl["width"], wl["height"]) if world > 1 else None
+    wk = Workload(pt, torch, wl, args, dev, local_rank, part)
+
+    if world > 1 and backend == "nccl":
+        # first use of a collective builds channels and loads its kernels: not part of a step
+        part.exchange(torch.zeros_like(wk.accum))
+    dt, st = timed_run(torch, dist, wk, args.steps, args.warmup, world, backend,
+                       exchange=(lambda: part.exchange(wk.accum)) if world > 1 else None)
+
+    samples_per_rank = wk.pixels() * wk.spp * args.steps
+    tdev = dev if backend == "nccl" else "cpu"
+    tot = torch.tensor([float(st["rays"]), float(samples_per_rank)], dtype=torch.float64, device=tdev)
+    if world > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    total_rays, total_samples = float(tot[0].item()), float(tot[1].item())
+    value = total_samples / dt / 1e6
+
+    out = None
+    if rank == 0:
+        next_frame = (args.warmup + args.steps) * wk.spp * world
+        roofline = wk.roofline(st, samples_per_rank, next_frame)
         # ---- CPU baseline: the oracle (C++ restatement, libm, f64) on this box's host cores ----
         cpu = None
         if args.cpu_seconds > 0 and world == 1:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import numpy as np
             import oracle_lib as O
-            oracle = O.OracleScene(data)
+            oracle = O.OracleScene(wk.data)
             threads = max(1, min(O.lib.orc_hardware_threads(), 16, len(os.sched_getaffinity(0))))
-            acc = np.zeros((args.height, args.width, 3))
-            cpu_cfg = pt.Config(width=args.width, height=args.height, bounces=args.bounces, seed=1, nee=args.nee)
+            acc = np.zeros((wk.h, wk.w, 3))
+            cpu_cfg = pt.Config(width=wk.w, height=wk.h, bounces=args.bounces, seed=1, nee=args.nee)
             n_frames, c0 = 0, time.perf_counter()
             while True:
                 oracle.render(cpu_cfg, acc, sample_begin=n_frames, sample_count=1, threads=threads, use_bvh=True)
@@ -286,28 +365,53 @@ def main():
                 if time.perf_counter() - c0 >= args.cpu_seconds:
                     break
             cdt = time.perf_counter() - c0
-            cpu = {"value": round(npix * n_frames / cdt / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
-                   "sample": f"{n_frames} frames (spp) of the same {args.width}x{args.height} {args.scene} workload, "
+            cpu = {"value": round(wk.w * wk.h * n_frames / cdt / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
+                   "sample": f"{n_frames} frames (spp) of the same {wk.w}x{wk.h} {wl['scene']} workload, "
                              f"{cdt:.1f} s; C++ f64 restatement of the Rust loop (rustc absent, SURVEY F1)"}
+            del oracle, acc
+        tiles = world > 1 and args.partition != "samples"
+        partitioning = "single GPU"
+        if world > 1:
+            partitioning = {"samples": "sample ranges, partial sums gathered and added in rank order on rank 0",
+                            "tiles": "interleaved groups of 8 rows, one gather to rank 0",
+                            "bands": "contiguous row bands, one gather to rank 0"}[args.partition]
         out = {
-            "metric": "Msamples/s", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": n_gpus,
+            "metric": "Msamples/s", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong" if tiles else "weak", "vs_baseline": None, "dtype": "f64",
-            "data": (f"synthetic heightfield box, {data.n_tris} triangles, seed 12345" if args.scene == "heightfield"
-                     else f"reference scene models/{args.scene}.obj") + ", counter-based RNG (no dataset)",
-            "config": {"workload": f"{args.scene}{'' if args.scene == 'heightfield' else '.obj'} {args.width}x{args.height} "
-                                   f"bounces={args.bounces}{', NEE' if args.nee else ''}{', textures' if args.textures else ''}, {args.spp} spp per step per GPU"
-                                   + (" (BASELINE.json configs[1])" if args.scene == "CornellBox" else ""),
-                       "triangles": data.n_tris,
+            "data": (f"synthetic heightfield box, {wk.data.n_tris} triangles, seed 12345" if wl["scene"] == "heightfield"
+                     else f"reference scene models/{wl['scene']}.obj") + ", counter-based RNG (no dataset)",
+            "config": {"workload": wk.describe(), "triangles": wk.data.n_tris,
                        "exact_culls": {k: os.environ.get(k, "1") != "0" for k in ("PT_SCREEN_CULL", "PT_LIGHT_CULL")},
-                       "partitioning": ("row-band tiles + one RCCL all-gather" if tiles else "sample ranges + one RCCL reduce") if world > 1 else "single GPU",
-                       "samples_per_step": band * args.width * args.spp * world},
+                       "partitioning": partitioning,
+                       "samples_per_step": int(total_samples / args.steps)},
             "mrays_per_s": round(total_rays / dt / 1e6, 3),
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
         if cpu:
             out["gpu_over_cpu"] = round(value / cpu["value"], 1) if cpu["value"] else None
+    del wk
+
+    # ---- the other BASELINE configs, a few steps each (single GPU only) ----------------------------------
+    if rank == 0 and world == 1 and args.configs == "all":
+        others = {}
+        for name, owl in WORKLOADS.items():
+            if name == args.workload:
+                continue
+            owk = Workload(pt, torch, dict(owl), args, dev, local_rank, None)
+            odt, ost = timed_run(torch, dist, owk, args.config_steps, 1, 1, backend)
+            n = owk.pixels() * owk.spp * args.config_steps
+            others[name] = {
+                "workload": owk.describe(), "triangles": owk.data.n_tris,
+                "value": round(n / odt / 1e6, 3), "unit": "Msamples/s", "steps": args.config_steps, "warmup": 1,
+                "ms_per_step": round(odt / args.config_steps * 1e3, 3),
+                "mrays_per_s": round(ost["rays"] / odt / 1e6, 3),
+                "roofline": owk.roofline(ost, n, (1 + args.config_steps) * owk.spp),
+            }
+            del owk
+        out["configs"] = others
+
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

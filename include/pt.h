@@ -175,6 +175,15 @@ typedef struct pt_render_params {
     uint64_t seed;            /* key of the counter-based RNG that replaces rand::random (F8) */
     double diff_size;         /* CONFIG.diff_size, default 0 (main.rs:348): spread of the differential
                                * rays spawned at Lambertian / Glossy vertices (PT_FLAG_PROPAGATE_DIFFS) */
+    /* Interleaved row partition (the frame closure of main.rs:409-432 cut across GPUs).
+     * With row_parts > 1 the call renders, of the tile's rows, only the groups of `row_group`
+     * consecutive rows (counted from y0) whose group number g has g % row_parts == row_index; the other
+     * rows of accum are not touched.  N calls with row_index 0..N-1 - one per GPU - cover the tile
+     * once, each GPU seeing every image region (a contiguous band per GPU leaves the ceiling's GPU
+     * idle while the floor's works).  row_group = 8 keeps the kernels' 8x8-pixel ray blocks whole.
+     * row_parts = 0 or 1: every row (the other two fields are ignored). */
+    uint32_t row_group, row_parts, row_index;
+    uint32_t reserved;        /* 0 */
 } pt_render_params;
 
 typedef struct pt_kernel_stat {

@@ -1111,6 +1111,8 @@ int orc_render(const orc_scene* s, const pt_render_params* P, double* accum, int
                 size_t c1 = std::min(npix, c0 + 32);
                 for (size_t k = c0; k < c1; ++k) {
                     uint32_t x = P->x0 + (uint32_t)(k % tw), y = P->y0 + (uint32_t)(k / tw);
+                    // interleaved row partition (pt.h pt_render_params::row_group / row_parts / row_index)
+                    if (P->row_parts > 1 && ((y - P->y0) / P->row_group) % P->row_parts != P->row_index) continue;
                     uint32_t pixel = y * P->width + x;
                     PixelArgs a = pixel_args(x, y, P->width, P->height, dx, dy);
                     V3 c = render(sc, a.x, a.y, a.ddx, a.ddy, pixel, sample, *P, use_bvh != 0);

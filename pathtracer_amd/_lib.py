@@ -70,7 +70,8 @@ class pt_render_params(C.Structure):
                 ("x0", C.c_uint32), ("y0", C.c_uint32), ("x1", C.c_uint32), ("y1", C.c_uint32),
                 ("sample_begin", C.c_uint64), ("sample_count", C.c_uint32),
                 ("max_bounces", C.c_uint32), ("flags", C.c_uint32), ("spp_per_batch", C.c_uint32),
-                ("seed", C.c_uint64), ("diff_size", C.c_double)]
+                ("seed", C.c_uint64), ("diff_size", C.c_double),
+                ("row_group", C.c_uint32), ("row_parts", C.c_uint32), ("row_index", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class pt_checkpoint_info(C.Structure):

@@ -309,6 +309,19 @@ int collect_timers(pt_scene* s) {
     return PT_OK;
 }
 
+// rows of a tile of `th` rows that a call renders (pt_render_params::row_group / row_parts / row_index)
+uint32_t owned_rows(const pt_render_params* p) {
+    const uint32_t th = p->y1 - p->y0;
+    if (p->row_parts <= 1) return th;
+    const uint32_t G = p->row_group, N = p->row_parts, r = p->row_index;
+    const uint32_t groups = (th + G - 1) / G;           // the last one may be short
+    if (r >= groups) return 0;
+    const uint32_t mine = (groups - r + N - 1) / N;     // groups r, r + N, ...
+    uint32_t rows = mine * G;
+    if ((groups - 1) % N == r) rows -= groups * G - th;  // the short last group is this call's
+    return rows;
+}
+
 int check_params(const pt_render_params* p) {
     if (!p) { set_error("null params"); return PT_ERR_INVALID; }
     if (p->width == 0 || p->height == 0 || (uint64_t)p->width * p->height >= (1ull << 32)) {
@@ -321,6 +334,10 @@ int check_params(const pt_render_params* p) {
     }
     if (p->max_bounces > kMaxBounces) { set_error("max_bounces > %u", kMaxBounces); return PT_ERR_UNSUPPORTED; }
     if ((uint64_t)(p->x1 - p->x0) * (p->y1 - p->y0) > (1ull << 30)) { set_error("tile too large"); return PT_ERR_UNSUPPORTED; }
+    if (p->row_parts > 1 && (p->row_group == 0 || p->row_index >= p->row_parts)) {
+        set_error("bad row partition: group %u, part %u of %u", p->row_group, p->row_index, p->row_parts);
+        return PT_ERR_INVALID;
+    }
     if ((p->flags & PT_FLAG_PROPAGATE_DIFFS) && !std::isfinite(p->diff_size)) {
         set_error("diff_size is not finite");
         return PT_ERR_INVALID;
@@ -742,7 +759,7 @@ namespace {
 // the scene's pool or are created, which is why the no-alloc entry point switches timers off).
 int render_batches(pt_scene* s, const pt_render_params* P, double* accum_dev, hipStream_t st, Workspace& w,
                    double* jitter, uint32_t spp, bool two, bool nee, bool diffs) {
-    const uint32_t tw = P->x1 - P->x0, th = P->y1 - P->y0;
+    const uint32_t tw = P->x1 - P->x0, th = owned_rows(P);  // the rows this call renders
     const uint32_t npix = tw * th;
     int rc = PT_OK;
     (void)rc;
@@ -802,6 +819,12 @@ int render_batches(pt_scene* s, const pt_render_params* P, double* accum_dev, hi
         ptd::Frame fr;
         fr.width = P->width; fr.height = P->height;
         fr.x0 = P->x0; fr.y0 = P->y0; fr.tile_w = tw; fr.tile_h = th;
+        fr.row_group = fr.row_off = fr.row_skip = 0;
+        if (P->row_parts > 1) {
+            fr.row_group = P->row_group;
+            fr.row_off = P->row_index * P->row_group;
+            fr.row_skip = (P->row_parts - 1) * P->row_group;
+        }
         fr.n_tile_pixels = npix;
         fr.n_samples = ns;
         fr.sample_base = P->sample_begin + b0;
@@ -885,8 +908,9 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
     if (!guard.ok) { set_error("hipSetDevice(%d) failed", s->device); return PT_ERR_DEVICE; }
     hipStream_t st = (hipStream_t)stream;
 
-    const uint32_t tw = P->x1 - P->x0, th = P->y1 - P->y0;
+    const uint32_t tw = P->x1 - P->x0, th = owned_rows(P);  // the rows this call renders
     const uint32_t npix = tw * th;
+    if (npix == 0) return PT_OK;  // a row partition with more parts than row groups
     const bool nee = (P->flags & PT_FLAG_NEE) != 0 && s->dev.n_lights > 0;
     // differentials only feed texture filtering: without a texture (or a second vertex) nothing reads them
     const bool diffs = (P->flags & PT_FLAG_PROPAGATE_DIFFS) && (P->flags & PT_FLAG_USE_DIFFS) && s->n_texs > 0 &&
@@ -979,7 +1003,8 @@ int pt_render_device_noalloc(pt_scene* s, const pt_render_params* P, double* acc
     if ((rc = scratch_address(s->device, &base)) != PT_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
 
-    const uint32_t npix = (P->x1 - P->x0) * (P->y1 - P->y0);
+    const uint32_t npix = (P->x1 - P->x0) * owned_rows(P);
+    if (npix == 0) return PT_OK;  // a row partition with more parts than row groups
     const bool nee = (P->flags & PT_FLAG_NEE) != 0 && s->dev.n_lights > 0;
     const bool diffs = (P->flags & PT_FLAG_PROPAGATE_DIFFS) && (P->flags & PT_FLAG_USE_DIFFS) && s->n_texs > 0 &&
                        P->max_bounces > 0;

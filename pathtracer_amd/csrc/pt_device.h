@@ -231,6 +231,12 @@ struct Frame {  // per-call constants of generate / shade
     uint32_t n_on_screen;            // pixels of the tile inside those bounds (the primary rays actually traced, per frame)
     uint32_t w8, h8, n8, bw, rw;     // tile_w & ~7, tile_h & ~7, w8 * h8, w8 / 8, tile_w - w8 (0 -> 1 for the divisor)
     FastDiv div_bw, div_rw;
+    // Interleaved row partition (pt_render_params::row_group / row_parts / row_index): tile_h counts only
+    // the rows this call renders, and tile row ty is image row y0 + row_off + ty + (ty / row_group) *
+    // row_skip, row_off = row_index * row_group, row_skip = (row_parts - 1) * row_group.  All zero = every
+    // row (tile row ty is image row y0 + ty).
+    uint32_t row_group, row_off, row_skip;
+    FastDiv div_group;
 };
 inline void finish_frame(Frame& fr) {  // (cx0..cy1 are set by the caller; default: no culling)
     fr.div_pixels = make_fastdiv(fr.n_tile_pixels ? fr.n_tile_pixels : 1u);
@@ -243,11 +249,19 @@ inline void finish_frame(Frame& fr) {  // (cx0..cy1 are set by the caller; defau
     fr.rw = fr.tile_w - fr.w8;
     fr.div_bw = make_fastdiv(fr.bw ? fr.bw : 1u);
     fr.div_rw = make_fastdiv(fr.rw ? fr.rw : 1u);
+    fr.div_group = make_fastdiv(fr.row_group ? fr.row_group : 1u);
     auto overlap = [](uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1) {
         uint32_t lo = a0 > b0 ? a0 : b0, hi = a1 < b1 ? a1 : b1;
         return hi > lo ? hi - lo : 0u;
     };
-    fr.n_on_screen = overlap(fr.x0, fr.x0 + fr.tile_w, fr.cx0, fr.cx1) * overlap(fr.y0, fr.y0 + fr.tile_h, fr.cy0, fr.cy1);
+    uint32_t rows = 0;  // tile rows inside the screen bounds
+    if (fr.row_skip == 0 && fr.row_off == 0) rows = overlap(fr.y0, fr.y0 + fr.tile_h, fr.cy0, fr.cy1);
+    else
+        for (uint32_t ty = 0; ty < fr.tile_h; ++ty) {
+            const uint32_t gy = fr.y0 + fr.row_off + ty + ty / fr.row_group * fr.row_skip;
+            rows += gy >= fr.cy0 && gy < fr.cy1;
+        }
+    fr.n_on_screen = overlap(fr.x0, fr.x0 + fr.tile_w, fr.cx0, fr.cx1) * rows;
 }
 
 struct Counters {  // device-side statistics (pt_stats)

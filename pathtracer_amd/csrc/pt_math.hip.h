@@ -72,6 +72,10 @@ struct PixelArgs {
     double x, y, ddx, ddy;
 };
 __device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) { return (uint32_t)(((unsigned long long)n * f.mul) >> f.shift); }
+// tile row -> image row (Frame: interleaved row partition; the identity + y0 for a plain tile)
+__device__ __forceinline__ uint32_t frame_row(const Frame& fr, uint32_t ty) {
+    return fr.y0 + fr.row_off + ty + fdiv(ty, fr.div_group) * fr.row_skip;
+}
 // slot within a frame -> pixel of the tile (Frame: 8x8 blocks, right strip, bottom rows)
 __device__ __forceinline__ void slot_pixel(const Frame& fr, uint32_t p, uint32_t& tx, uint32_t& ty) {
     if (p < fr.n8) {

@@ -16,7 +16,7 @@ __global__ __launch_bounds__(kBlock) void k_generate_rays(Scene sc, Frame fr, do
     uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= fr.n_tile_pixels) return;
     uint32_t ty = fdiv(p, fr.div_tile_w), tx = p - ty * fr.tile_w;
-    PixelArgs a = pixel_args(fr.x0 + tx, fr.y0 + ty, fr.width, fr.height, fr.jitter[0], fr.jitter[1], fr.aspect);
+    PixelArgs a = pixel_args(fr.x0 + tx, frame_row(fr, ty), fr.width, fr.height, fr.jitter[0], fr.jitter[1], fr.aspect);
     D3 dir = camera_dir(sc.cam, a.x, a.y);
     double* r = rays + (size_t)p * 8;
     r[0] = sc.cam.eye[0]; r[1] = sc.cam.eye[1]; r[2] = sc.cam.eye[2];
@@ -502,12 +502,13 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
     uint32_t s = fdiv(slot, fr.div_pixels), p = slot - s * fr.n_tile_pixels;
     uint32_t ty, tx;
     slot_pixel(fr, p, tx, ty);
-    uint32_t pixel = (fr.y0 + ty) * fr.width + fr.x0 + tx;
+    const uint32_t gy_ = frame_row(fr, ty);
+    uint32_t pixel = gy_ * fr.width + fr.x0 + tx;
     uint64_t sample = fr.sample_base + s;
     constexpr bool kNeedRay = !LAST || NEE;
     if (!FUSED) {  // FUSED: the caller traced the ray in this kernel and still holds it
         if (FIRST) {
-            PixelArgs a = pixel_args(fr.x0 + tx, fr.y0 + ty, fr.width, fr.height, fr.jitter[2 * s], fr.jitter[2 * s + 1], fr.aspect);
+            PixelArgs a = pixel_args(fr.x0 + tx, gy_, fr.width, fr.height, fr.jitter[2 * s], fr.jitter[2 * s + 1], fr.aspect);
             o = ld3(sc.cam.eye);
             d = camera_dir(sc.cam, a.x, a.y);
         } else if (kNeedRay) {
@@ -839,7 +840,7 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value)) void k_path(Scene g
                 uint32_t s = fdiv(i, fr.div_pixels), p = i - s * fr.n_tile_pixels;
                 uint32_t ty, tx;
                 slot_pixel(fr, p, tx, ty);
-                const uint32_t gx = fr.x0 + tx, gy = fr.y0 + ty;
+                const uint32_t gx = fr.x0 + tx, gy = frame_row(fr, ty);
                 on_screen = gx >= fr.cx0 && gx < fr.cx1 && gy >= fr.cy0 && gy < fr.cy1;
                 if (on_screen) {
                     PixelArgs a = pixel_args(gx, gy, fr.width, fr.height, fr.jitter[2 * s], fr.jitter[2 * s + 1], fr.aspect);
@@ -901,7 +902,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(Frame fr, Sample3 ls, con
     uint32_t n_lit = 0;
     uint32_t ty, tx;
     slot_pixel(fr, slot_in_frame, tx, ty);
-    size_t pix = (size_t)(fr.y0 + ty) * fr.width + fr.x0 + tx;
+    size_t pix = (size_t)frame_row(fr, ty) * fr.width + fr.x0 + tx;
     double r = accum[pix * 3], g = accum[pix * 3 + 1], b = accum[pix * 3 + 2];
     bool drop = (fr.flags & PT_FLAG_DROP_NONFINITE) != 0;
     // frames in index order; the bitmap words of eight frames are fetched together (independent loads),

@@ -508,7 +508,7 @@ __global__ __launch_bounds__(kTravBlock) void k_extend(Scene sc, Frame fr, Queue
                 uint32_t s = fdiv(i, fr.div_pixels), p = i - s * fr.n_tile_pixels;
                 uint32_t ty, tx;
                 slot_pixel(fr, p, tx, ty);
-                const uint32_t gx = fr.x0 + tx, gy = fr.y0 + ty;
+                const uint32_t gx = fr.x0 + tx, gy = frame_row(fr, ty);
                 PixelArgs a = pixel_args(gx, gy, fr.width, fr.height, fr.jitter[2 * s], fr.jitter[2 * s + 1], fr.aspect);
                 o = ld3(sc.cam.eye);
                 d = camera_dir(sc.cam, a.x, a.y);

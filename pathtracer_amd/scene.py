@@ -93,7 +93,8 @@ class Config:
             f |= L.PT_FLAG_ROUGHDIFF
         return f
 
-    def params(self, sample_begin: int, sample_count: int, tile=None) -> L.pt_render_params:
+    def params(self, sample_begin: int, sample_count: int, tile=None, rows=None) -> L.pt_render_params:
+        """``rows`` = (row_group, row_parts, row_index): the interleaved row partition of pt_render_params."""
         x0, y0, x1, y1 = tile if tile is not None else (0, 0, self.w, self.h)
         p = L.pt_render_params()
         p.width, p.height = self.w, self.h
@@ -104,6 +105,8 @@ class Config:
         p.spp_per_batch = self.spp_per_batch
         p.seed = self.seed
         p.diff_size = self.diff_size
+        if rows is not None:
+            p.row_group, p.row_parts, p.row_index = rows
         return p
 
 
@@ -295,20 +298,20 @@ class Scene:
 
     # -- main.rs:400-436 -------------------------------------------------------------------------
     def render(self, cfg: Config, accum: Optional[np.ndarray] = None, sample_begin: int = 0,
-               sample_count: Optional[int] = None, tile=None) -> np.ndarray:
+               sample_count: Optional[int] = None, tile=None, rows=None) -> np.ndarray:
         """Adds ``sample_count`` frames to ``accum`` (h, w, 3 float64, ``pixels[i] += next[i]``)."""
         if accum is None:
             accum = np.zeros((cfg.h, cfg.w, 3), dtype=np.float64)
         assert accum.dtype == np.float64 and accum.flags.c_contiguous and accum.size == cfg.w * cfg.h * 3
         n = cfg.samples_pr_pixel if sample_count is None else sample_count
-        p = cfg.params(sample_begin, n, tile)
+        p = cfg.params(sample_begin, n, tile, rows)
         L.check(L.lib.pt_render(self._h, C.byref(p), _ptr(accum, C.c_double)))
         return accum
 
     def render_device(self, cfg: Config, accum_ptr: int, sample_begin: int, sample_count: int, tile=None,
-                      stream: int = 0) -> None:
+                      stream: int = 0, rows=None) -> None:
         """Same, into a device buffer (e.g. ``torch.Tensor.data_ptr()``) on ``stream``."""
-        p = cfg.params(sample_begin, sample_count, tile)
+        p = cfg.params(sample_begin, sample_count, tile, rows)
         L.check(L.lib.pt_render_device(self._h, C.byref(p), C.c_void_p(accum_ptr), C.c_void_p(stream)))
 
     def render_device_noalloc(self, cfg: Config, accum_ptr: int, sample_begin: int, sample_count: int, tile=None,

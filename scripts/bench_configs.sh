@@ -12,4 +12,4 @@ run glossy --scene glossy_planes --steps 20 --warmup 2 --spp 32 || exit 1
 run glossy_nee --scene glossy_planes --nee --steps 20 --warmup 2 --spp 32 || exit 1
 run test4k_tex --scene Test --textures --width 3840 --height 2160 --steps 10 --warmup 2 --spp 8 || exit 1
 run test4k_tex_nee --scene Test --textures --nee --width 3840 --height 2160 --steps 10 --warmup 2 --spp 8 || exit 1
-run hf_nee --scene heightfield --width 3840 --height 2160 --nee --steps 4 --warmup 1 --spp 8 || exit 1
+run hf_nee --workload heightfield --nee --steps 4 --warmup 1 --spp 8 || exit 1

@@ -6,7 +6,7 @@ run() {  # $1 label, rest: bench args
   python -c "
 import json;d=json.load(open('/tmp/sweep.json'));r=d['roofline'];print('$label', d['value'], d['ms_per_step'], r['kernel_ms'])"
 }
-H="--scene heightfield --width 3840 --height 2160 --spp 16 --steps 5 --warmup 1"
+H="--workload heightfield --spp 16 --batch 16 --steps 5 --warmup 1"
 for cfg in "$@"; do
   ( export $cfg
     run "cornell [$cfg]"

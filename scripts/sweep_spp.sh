@@ -3,7 +3,7 @@
 # size separates a fixed tail from per-ray cost
 for SPP in 8 16; do
   for PIPE in 0 1; do
-  PT_PIPELINE=$PIPE timeout -k 10 300 python bench.py --scene heightfield --width 3840 --height 2160 --spp $SPP --steps 4 --warmup 1 --cpu-seconds 0 > /tmp/s.json 2> /tmp/s.err || { tail -3 /tmp/s.err; exit 1; }
+  PT_PIPELINE=$PIPE timeout -k 10 300 python bench.py --workload heightfield --spp $SPP --steps 4 --warmup 1 --cpu-seconds 0 > /tmp/s.json 2> /tmp/s.err || { tail -3 /tmp/s.err; exit 1; }
   python -c "
 import json;d=json.load(open('/tmp/s.json'));r=d['roofline'];print('hf spp $SPP pipe $PIPE', d['value'], d['ms_per_step'], {k:round(v/4,3) for k,v in r['kernel_ms'].items()})"
   done

@@ -112,11 +112,12 @@ class OracleScene:
         lib.orc_generate_rays(self._h, C.byref(p), sample, C.cast(rays.ctypes.data, _P(L.pt_ray)))
         return rays
 
-    def render(self, cfg: Config, accum=None, sample_begin=0, sample_count=None, tile=None, threads=8, use_bvh=False):
+    def render(self, cfg: Config, accum=None, sample_begin=0, sample_count=None, tile=None, threads=8, use_bvh=False,
+               rows=None):
         if accum is None:
             accum = np.zeros((cfg.h, cfg.w, 3), np.float64)
         n = cfg.samples_pr_pixel if sample_count is None else sample_count
-        p = cfg.params(sample_begin, n, tile)
+        p = cfg.params(sample_begin, n, tile, rows)
         lib.orc_render(self._h, C.byref(p), _ptr(accum, C.c_double), threads, int(use_bvh))
         return accum
 

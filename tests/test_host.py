@@ -35,7 +35,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(L.pt_bvh_node) == 64
     assert C.sizeof(L.pt_ray) == 64
     assert C.sizeof(L.pt_material) == 40
-    assert C.sizeof(L.pt_render_params) == 64
+    assert C.sizeof(L.pt_render_params) == 80
     assert C.sizeof(L.pt_camera) == 80
 
 
