@@ -82,8 +82,10 @@ typedef struct pt_camera {
 } pt_camera;
 
 /* Flattened two-child BVH node (64 B = four 16-byte loads).  bounds = {lo0,hi0,lo1,hi1} of the
- * two children, f32 like the reference's external bvh crate (bvh.rs:37,98-101), padded outward
- * by the builder so an f64 slab test never culls a triangle the f64 triangle test accepts.
+ * two children, f32 like the reference's external bvh crate (bvh.rs:37,98-101).  The kernels test
+ * boxes in f32 as a pure cull (the f64 triangle test alone decides hits) and need every box to stand
+ * 2^-21 of the scene's largest |coordinate| clear of its triangles: pt_bvh_build stores its boxes that
+ * way, and pt_scene_create widens a caller's boxes by that margin itself (tight boxes are fine).
  * child >= 0: index of an inner node.  child < 0: leaf, ~child = (first << 3) | (count - 1),
  * a run of `count` (1..8) entries of bvh_tri_order.  PT_BVH_EMPTY: no child. */
 #define PT_BVH_EMPTY 0x7FFFFFFF

@@ -438,6 +438,7 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
         if (!d->bvh_tri_order && d->n_tris) { set_error("bvh_nodes given without bvh_tri_order"); return PT_ERR_INVALID; }
         s->nodes.assign(d->bvh_nodes, d->bvh_nodes + d->n_bvh_nodes);
         s->order.assign(d->bvh_tri_order, d->bvh_tri_order + d->n_tris);
+        pth::bvh_widen(s->nodes, d->verts, d->n_verts);  // the margin the f32 box tests need (pt_bvh.cpp)
     } else {
         // leaves of at most 2 triangles (a quad): measured against 1/3/4/8 on both bench scenes
         // (CornellBox 13.3/13.6/11.6/11.5, 10 M triangles 3.03/3.42/3.16/2.84 Gsamples/s; 2: 13.6/3.43)
@@ -748,6 +749,26 @@ void screen_bounds(const pt_scene* s, uint32_t width, uint32_t height, ptd::Fram
     fr.cy0 = clampi(std::floor(py0) - 2., height);
     fr.cy1 = clampi(std::ceil(py1) + 3., height);
 }
+
+// The tile a render call works on: the caller's, cut down to the scene's screen bounds.  A primary ray
+// through a pixel outside them hits nothing and adds the background (main.rs:299) - with a black
+// background +-0, which leaves the pixel's sum as it is - so such pixels are left out of the tile: no
+// slots, no idle lanes in the bounce-0 launch, no share of k_accumulate for them (CornellBox at 16:9:
+// 44 % of the columns).  Only with a black background.  Rows are cut only without a row partition (its
+// groups are counted from y0).
+pt_render_params clip_to_screen(const pt_scene* s, const pt_render_params* P) {
+    pt_render_params Q = *P;
+    if (s->dev.background[0] != 0. || s->dev.background[1] != 0. || s->dev.background[2] != 0.) return Q;
+    ptd::Frame fr{};
+    screen_bounds(s, P->width, P->height, fr);
+    Q.x0 = std::max(P->x0, fr.cx0);
+    Q.x1 = std::max(Q.x0, std::min(P->x1, fr.cx1));
+    if (P->row_parts <= 1) {
+        Q.y0 = std::max(P->y0, fr.cy0);
+        Q.y1 = std::max(Q.y0, std::min(P->y1, fr.cy1));
+    }
+    return Q;
+}
 }  // namespace
 
 }  // extern "C"
@@ -898,19 +919,23 @@ int render_batches(pt_scene* s, const pt_render_params* P, double* accum_dev, hi
 
 extern "C" {
 
-int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, void* stream) {
+int pt_render_device(pt_scene* s, const pt_render_params* P_in, double* accum_dev, void* stream) {
     if (!s || !accum_dev) { set_error("null argument"); return PT_ERR_INVALID; }
-    int rc = check_params(P);
+    int rc = check_params(P_in);
     if (rc != PT_OK) return rc;
-    if (P->sample_count == 0) return PT_OK;
+    if (P_in->sample_count == 0) return PT_OK;
     std::lock_guard<std::mutex> lk(s->mu);
     DeviceGuard guard(s->device);
     if (!guard.ok) { set_error("hipSetDevice(%d) failed", s->device); return PT_ERR_DEVICE; }
     hipStream_t st = (hipStream_t)stream;
 
+    const uint64_t n_asked = (uint64_t)(P_in->x1 - P_in->x0) * owned_rows(P_in) * P_in->sample_count;
+    const pt_render_params clipped = clip_to_screen(s, P_in);
+    const pt_render_params* P = &clipped;
     const uint32_t tw = P->x1 - P->x0, th = owned_rows(P);  // the rows this call renders
     const uint32_t npix = tw * th;
-    if (npix == 0) return PT_OK;  // a row partition with more parts than row groups
+    s->stats.samples += n_asked;
+    if (npix == 0) return PT_OK;  // nothing of the tile on screen, or a row partition with more parts than row groups
     const bool nee = (P->flags & PT_FLAG_NEE) != 0 && s->dev.n_lights > 0;
     // differentials only feed texture filtering: without a texture (or a second vertex) nothing reads them
     const bool diffs = (P->flags & PT_FLAG_PROPAGATE_DIFFS) && (P->flags & PT_FLAG_USE_DIFFS) && s->n_texs > 0 &&
@@ -949,7 +974,6 @@ int pt_render_device(pt_scene* s, const pt_render_params* P, double* accum_dev, 
     if (rc != PT_OK) return rc;
     HIP_TRY(hipEventRecord(s->ws_free, st));
     s->ws_used = true;
-    s->stats.samples += (uint64_t)npix * P->sample_count;
     if (s->timed.size() >= kMaxPendingTimers) return collect_timers(s);
     return PT_OK;
 }
@@ -991,11 +1015,14 @@ int scratch_address(int dev, unsigned char** out) {
 
 extern "C" {
 
-int pt_render_device_noalloc(pt_scene* s, const pt_render_params* P, double* accum_dev, void* stream) {
+int pt_render_device_noalloc(pt_scene* s, const pt_render_params* P_in, double* accum_dev, void* stream) {
     if (!s || !accum_dev) { set_error("null argument"); return PT_ERR_INVALID; }
-    int rc = check_params(P);
+    int rc = check_params(P_in);
     if (rc != PT_OK) return rc;
-    if (P->sample_count == 0) return PT_OK;
+    if (P_in->sample_count == 0) return PT_OK;
+    const uint64_t n_asked = (uint64_t)(P_in->x1 - P_in->x0) * owned_rows(P_in) * P_in->sample_count;
+    const pt_render_params clipped = clip_to_screen(s, P_in);
+    const pt_render_params* P = &clipped;
     std::lock_guard<std::mutex> lk(s->mu);
     DeviceGuard guard(s->device);
     if (!guard.ok) { set_error("hipSetDevice(%d) failed", s->device); return PT_ERR_DEVICE; }
@@ -1004,7 +1031,7 @@ int pt_render_device_noalloc(pt_scene* s, const pt_render_params* P, double* acc
     hipStream_t st = (hipStream_t)stream;
 
     const uint32_t npix = (P->x1 - P->x0) * owned_rows(P);
-    if (npix == 0) return PT_OK;  // a row partition with more parts than row groups
+    if (npix == 0) { s->stats.samples += n_asked; return PT_OK; }  // nothing on screen / an empty row partition
     const bool nee = (P->flags & PT_FLAG_NEE) != 0 && s->dev.n_lights > 0;
     const bool diffs = (P->flags & PT_FLAG_PROPAGATE_DIFFS) && (P->flags & PT_FLAG_USE_DIFFS) && s->n_texs > 0 &&
                        P->max_bounces > 0;
@@ -1040,7 +1067,7 @@ int pt_render_device_noalloc(pt_scene* s, const pt_render_params* P, double* acc
     rc = render_batches(s, P, accum_dev, st, w, (double*)base, spp, false, nee, diffs);
     s->timers_off = false;
     if (rc != PT_OK) return rc;
-    s->stats.samples += (uint64_t)npix * P->sample_count;
+    s->stats.samples += n_asked;
     return PT_OK;
 }
 

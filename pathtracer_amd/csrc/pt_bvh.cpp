@@ -408,6 +408,26 @@ int bvh_build(const float* verts, uint32_t n_verts, const uint32_t* tris, uint32
     return PT_OK;
 }
 
+// A caller's tree (pt_scene_desc::bvh_nodes) holds whatever boxes its builder made - tight ones, as a
+// rule.  The traversal kernels test boxes in f32 and rely on every box standing `pad` = 2^-21 of the
+// scene's largest |coordinate| clear of its triangles (pt_traverse.hip.h slab32), which is what the
+// library's own builder stores; a caller's boxes are therefore widened by that pad here, rounded
+// outward.  Widening an already padded tree again costs a few more opened boxes, nothing else.
+void bvh_widen(std::vector<pt_bvh_node>& nodes, const float* verts, uint32_t n_verts) {
+    double max_abs = 0.;
+    for (size_t i = 0; i < (size_t)n_verts * 3; ++i)
+        if (std::isfinite(verts[i])) max_abs = std::max(max_abs, (double)std::fabs(verts[i]));
+    const double pad = std::max(max_abs, 1e-30) * (1.0 / 2097152.0);
+    for (auto& n : nodes)
+        for (int c = 0; c < 2; ++c) {
+            if (n.child[c] == PT_BVH_EMPTY) continue;
+            for (int a = 0; a < 3; ++a) {
+                n.bounds[c * 6 + a] = round_down((double)n.bounds[c * 6 + a] - pad);
+                n.bounds[c * 6 + 3 + a] = round_up((double)n.bounds[c * 6 + 3 + a] + pad);
+            }
+        }
+}
+
 // Walks a BVH (the library's or a caller's) and checks everything the extend kernel assumes:
 // child indices in range, no cycles (each inner node reached once), leaf runs inside
 // [0, n_tris), every triangle referenced exactly once, depth within the LDS stack.

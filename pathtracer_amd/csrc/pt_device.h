@@ -58,11 +58,12 @@ struct TriShade {
 // Primary rays all start at the eye, so everything in the slab and triangle tests that depends on
 // the origin but not on the direction is the same for every one of them: child boxes relative to
 // the eye, and per triangle e0, e1, e0 x e1, v0 - o and (v0 - o).(e0 x e1).  These tables hold
-// those values in f64, computed on the device by the expressions of the general tests, so the
-// specialised tests give the same bits with about a third fewer instructions.  Built for scenes of
-// up to kEyeTableMaxTris triangles (112 B per node and per triangle).
+// those values (triangles in f64, computed on the device by the expressions of the general test, so the
+// specialised test gives the same bits with about a third fewer instructions; boxes in f32, rounded
+// outward: the box test is only a cull).  Built for scenes of up to kEyeTableMaxTris triangles (64 B
+// per node, 112 B per triangle).
 struct EyeNode {
-    double rel[12];  // child 0: lo - o (xyz), hi - o (xyz); child 1 likewise
+    float rel[12];  // child 0: lo - o (xyz), hi - o (xyz), rounded outward to f32 (pt_traverse.hip.h slab_rel); child 1 likewise
     int32_t child[2];
     uint32_t pad[2];
 };

@@ -778,9 +778,9 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value)) void k_path(Scene g
     __shared__ float4 s_tris[LDS ? kLdsScene * 3 : 1];
     __shared__ float4 s_shade[LDS ? kLdsScene * 2 : 1];
     __shared__ double s_mats[LDS ? kLdsMats * kMatWords : 1];
-    __shared__ float4 s_eye_nodes[(LDS && FIRST) ? kLdsScene * 7 : 1];
+    __shared__ float4 s_eye_nodes[(LDS && FIRST) ? kLdsScene * 4 : 1];
     __shared__ float4 s_eye_tris[(LDS && FIRST) ? kLdsScene * 7 : 1];
-    static_assert(sizeof(TriShade) == 32 && sizeof(EyeNode) == 112 && sizeof(EyeTri) == 112 && sizeof(Material) % 8 == 0, "LDS copies");
+    static_assert(sizeof(TriShade) == 32 && sizeof(EyeNode) == 64 && sizeof(EyeTri) == 112 && sizeof(Material) % 8 == 0, "LDS copies");
     Scene sc = gsc;
     if (LDS) {  // pointers first (compile-time: the address space is then known at every use), data below
         sc.nodes = s_nodes;
@@ -826,7 +826,7 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value)) void k_path(Scene g
             if (FIRST) {
                 const float4* g_en = reinterpret_cast<const float4*>(gsc.eye_nodes);
                 const float4* g_et = reinterpret_cast<const float4*>(gsc.eye_tris);
-                for (uint32_t k = threadIdx.x; k < gsc.n_nodes * 7; k += kPathBlock) s_eye_nodes[k] = g_en[k];
+                for (uint32_t k = threadIdx.x; k < gsc.n_nodes * 4; k += kPathBlock) s_eye_nodes[k] = g_en[k];
                 for (uint32_t k = threadIdx.x; k < gsc.n_tris * 7; k += kPathBlock) s_eye_tris[k] = g_et[k];
             }
             __syncthreads();

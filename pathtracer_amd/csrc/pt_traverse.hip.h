@@ -68,16 +68,51 @@ __device__ __forceinline__ bool tri_test(const TriV& tr, D3 o, D3 d, double t_mi
     return tri_test_core(tri_pre(tr, o), d, t_min, t_max, t_out, v_out, w_out);
 }
 
-// f64 slab test against an f32 box that the builder padded outward.  v_min/v_max_f64 return the
-// non-NaN operand, so a 0*inf (origin on a padded plane, parallel ray) yields a miss, which is
-// right: the padded plane holds no triangle of the box.
-__device__ __forceinline__ bool slab(double lox, double loy, double loz, double hix, double hiy, double hiz, D3 o,
-                                     D3 inv, double t_min, double t_max, double& t_near) {
-    double ax = (lox - o.x) * inv.x, bx = (hix - o.x) * inv.x;
-    double ay = (loy - o.y) * inv.y, by = (hiy - o.y) * inv.y;
-    double az = (loz - o.z) * inv.z, bz = (hiz - o.z) * inv.z;
-    double tn = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmax(fmin(az, bz), t_min));
-    double tf = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmin(fmax(az, bz), t_max));
+// The box test is a pure cull - it decides which boxes are opened, the f64 triangle test alone decides
+// what is hit - so it runs in f32, at twice the f64 rate and without widening the f32 boxes
+// (v_cvt_f64_f32 costs more than the subtraction it feeds).  It must never reject a box that holds a
+// triangle the f64 test accepts.  Why it cannot:
+//   * a hit point p = o + t d lies in the triangles' own box U; the stored box [lo, hi] is U widened by
+//     pad = 2^-21 M per side (M = the scene's largest |coordinate|, pt_bvh.cpp / bvh_pad), so along every
+//     axis with d != 0 the plane distances satisfy t_lo + pad |1/d| <= t <= t_hi - pad |1/d|;
+//   * the ray's origin is taken twice, ol = fl(o + E) for the lo planes and oh = fl(o - E) for the hi
+//     planes, E = 2^-21 max|o_k|: after rounding still >= 6.9 u max|o_k| beyond o (u = 2^-24), i.e. the box
+//     is widened by a further ~7 u |o| on every side;
+//   * a' = fl(fl(lo - ol) * fl(1/d)) carries three roundings: |a' - (lo - ol)/d| <= 3 u |lo - ol| / |d|
+//     <= 3 u (M + 1.0001 |o|) / |d|, which is below the (8 u M + 6.9 u |o|) / |d| of slack.  So a' <= t
+//     on the entry side and b' >= t on the exit side of every axis: max(a') <= t <= min(b');
+//   * t_min is rounded down and t_max up to f32, so they still bracket t;
+//   * d_k == 0, or 1/d_k beyond the f32 range: the factor is +-inf and the numerators of a box that holds
+//     the hit are strictly negative (lo) and positive (hi) by the same slack, so the axis gives
+//     [-inf, +inf].  A 0 * inf = NaN can only arise for a box the ray cannot hit; v_min/v_max_f32
+//     return the non-NaN operand and either outcome is then right.
+// A box opened without need costs time, never correctness.
+struct RayF {
+    float olx, oly, olz;  // fl(o + E): subtracted from the lo planes
+    float ohx, ohy, ohz;  // fl(o - E): subtracted from the hi planes
+    float ix, iy, iz;     // fl(1 / d)
+};
+__device__ __forceinline__ float f32_up(double x) {  // smallest f32 >= x (x not NaN)
+    float f = (float)x;
+    if ((double)f < x) f = f >= 0.f ? __uint_as_float(__float_as_uint(f) + 1u) : __uint_as_float(__float_as_uint(f) - 1u);
+    return f;
+}
+__device__ __forceinline__ float f32_down(double x) { return -f32_up(-x); }
+__device__ __forceinline__ RayF make_rayf(D3 o, D3 d) {
+    const double E = fmax(fmax(fabs(o.x), fabs(o.y)), fabs(o.z)) * 0x1p-21;
+    RayF r;
+    r.olx = (float)(o.x + E); r.oly = (float)(o.y + E); r.olz = (float)(o.z + E);
+    r.ohx = (float)(o.x - E); r.ohy = (float)(o.y - E); r.ohz = (float)(o.z - E);
+    r.ix = (float)(1. / d.x); r.iy = (float)(1. / d.y); r.iz = (float)(1. / d.z);
+    return r;
+}
+__device__ __forceinline__ bool slab32(float lox, float loy, float loz, float hix, float hiy, float hiz, const RayF& r,
+                                       float t_min, float t_max, float& t_near) {
+    float ax = (lox - r.olx) * r.ix, bx = (hix - r.ohx) * r.ix;
+    float ay = (loy - r.oly) * r.iy, by = (hiy - r.ohy) * r.iy;
+    float az = (loz - r.olz) * r.iz, bz = (hiz - r.ohz) * r.iz;
+    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), t_min));
+    float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), t_max));
     t_near = tn;
     return tn <= tf;
 }
@@ -141,16 +176,14 @@ extern "C" int pt_debug_stack_overflows(unsigned int* out) {
 #define PT_STACK_CHECK(sp, depth) ((void)0)
 #endif
 template <int DEPTH, bool STATS, int STRIDE = kTravBlock>
-__device__ __forceinline__ int node_step(const Scene& sc, int cur, D3 o, D3 inv, double t_min, double t_max, int* stk,
+__device__ __forceinline__ int node_step(const Scene& sc, int cur, const RayF& rf, float t_min, float t_max, int* stk,
                                          int& sp, uint32_t& n_nodes) {
     const float4* np = sc.nodes + (size_t)cur * 4;
     float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
     int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-    double tn0, tn1;
-    bool h0 = slab((double)n0.x, (double)n0.y, (double)n0.z, (double)n0.w, (double)n1.x, (double)n1.y, o, inv, t_min,
-                   t_max, tn0) && c0 != PT_BVH_EMPTY;
-    bool h1 = slab((double)n1.z, (double)n1.w, (double)n2.x, (double)n2.y, (double)n2.z, (double)n2.w, o, inv, t_min,
-                   t_max, tn1) && c1 != PT_BVH_EMPTY;
+    float tn0, tn1;
+    bool h0 = slab32(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, rf, t_min, t_max, tn0) && c0 != PT_BVH_EMPTY;
+    bool h1 = slab32(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, rf, t_min, t_max, tn1) && c1 != PT_BVH_EMPTY;
     if (STATS) n_nodes += 2;
     if (h0 && h1) {
         int nearc = c0, farc = c1;
@@ -230,8 +263,10 @@ __device__ __forceinline__ void trace_range_vote(const Scene& sc, uint32_t begin
     bool more = pool.cursors != nullptr;  // wave-uniform: the pool may hold further ranges
     bool busy = false;
     uint32_t idx = 0, best = PT_MISS, best_id = PT_MISS;
-    D3 o = mk(0., 0., 0.), d = o, inv = o;
+    D3 o = mk(0., 0., 0.), d = o;
+    RayF rf = make_rayf(o, o);
     double t_min = 0., t_max = 0.;
+    float t_min32 = 0.f, t_max32 = 0.f;  // t_min rounded down, t_max rounded up (slab32)
     int sp = 0, cur = kDone;
     for (;;) {
         if (more && cursor >= end) {  // the range is handed out: claim the next one (lanes still at work keep going)
@@ -244,7 +279,7 @@ __device__ __forceinline__ void trace_range_vote(const Scene& sc, uint32_t begin
         const int n_node = __popcll(__ballot(is_node)), n_tri = __popcll(__ballot(is_tri)), n_ret = __popcll(m_ret);
         if (n_node >= n_tri && n_node >= n_ret) {
             if (n_node == 0) break;  // nothing left in the range
-            if (is_node) cur = node_step<DEPTH, STATS>(sc, cur, o, inv, t_min, t_max, stk, sp, n_nodes);
+            if (is_node) cur = node_step<DEPTH, STATS>(sc, cur, rf, t_min32, t_max32, stk, sp, n_nodes);
         } else if (n_tri >= n_ret) {
             if (is_tri) {
                 uint32_t code = (uint32_t)~cur, first = code >> 3, cnt = (code & 7u) + 1u;
@@ -261,6 +296,7 @@ __device__ __forceinline__ void trace_range_vote(const Scene& sc, uint32_t begin
                     // tested last; the build-defined rule keeps the lowest triangle id
                     if (best != PT_MISS && !(t < t_max || gid < best_id)) continue;
                     best = first + k; best_id = gid; t_max = t;
+                    t_max32 = f32_up(t);
                     if (ANY) { stop = true; break; }
                 }
                 if (stop || sp == 0) cur = kDone;
@@ -275,7 +311,7 @@ __device__ __forceinline__ void trace_range_vote(const Scene& sc, uint32_t begin
                 if (cand < end) {
                     idx = cand;
                     fetch(idx, o, d, t_min, t_max);
-                    inv = mk(1. / d.x, 1. / d.y, 1. / d.z);
+                    rf = make_rayf(o, d);
                     best = PT_MISS; best_id = PT_MISS;
                     sp = 0;
                     cur = sc.n_nodes ? 0 : kDone;
@@ -283,6 +319,8 @@ __device__ __forceinline__ void trace_range_vote(const Scene& sc, uint32_t begin
                         prims_closest(sc, o, d, t_min, t_max, best, best_id);
                         if (ANY && best != PT_MISS) cur = kDone;
                     }
+                    t_min32 = f32_down(t_min);
+                    t_max32 = f32_up(t_max);
                     busy = true;
                 }
             }
@@ -306,11 +344,13 @@ __device__ __forceinline__ uint32_t traverse(const Scene& sc, D3 o, D3 d, double
         if (ANY && best != PT_MISS) return best;
     }
     if (sc.n_nodes == 0) return best;
-    D3 inv = mk(1. / d.x, 1. / d.y, 1. / d.z);
+    const RayF rf = make_rayf(o, d);
+    const float t_min32 = f32_down(t_min);
+    float t_max32 = f32_up(t_max);
     int sp = 0;
     int cur = 0;
     while (cur != kDone) {
-        while (cur >= 0) cur = node_step<DEPTH, STATS, STRIDE>(sc, cur, o, inv, t_min, t_max, stk, sp, n_nodes);
+        while (cur >= 0) cur = node_step<DEPTH, STATS, STRIDE>(sc, cur, rf, t_min32, t_max32, stk, sp, n_nodes);
         if (cur == kDone) break;
         int code = ~cur;
         uint32_t first = (uint32_t)code >> 3, cnt = ((uint32_t)code & 7u) + 1u;
@@ -326,6 +366,7 @@ __device__ __forceinline__ uint32_t traverse(const Scene& sc, D3 o, D3 d, double
             // tested last; the build-defined rule keeps the lowest triangle id
             if (best != PT_MISS && !(t < t_max || gid < best_id)) continue;
             best = first + k; best_id = gid; t_max = t;
+            t_max32 = f32_up(t);
             if (ANY) return best;
         }
         if (sp == 0) break;
@@ -336,12 +377,15 @@ __device__ __forceinline__ uint32_t traverse(const Scene& sc, D3 o, D3 d, double
 }
 
 // ---- primary rays of a small scene: the eye-relative tables (pt_device.h EyeNode / EyeTri) -----
-__device__ __forceinline__ bool slab_rel(const double* r, D3 inv, double t_min, double t_max, double& t_near) {
-    double ax = r[0] * inv.x, bx = r[3] * inv.x;   // r = (lo - o, hi - o): the subtraction of slab() is in the table
-    double ay = r[1] * inv.y, by = r[4] * inv.y;
-    double az = r[2] * inv.z, bz = r[5] * inv.z;
-    double tn = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmax(fmin(az, bz), t_min));
-    double tf = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmin(fmax(az, bz), t_max));
+// slab32 with the subtraction done once per scene: r = (lo - o - E, hi - o + E) rounded outward to f32 by
+// k_build_eye_tables (directed, so only the two roundings of fl(r * fl(1/d)) remain: 2 u |r| of error
+// against 8 u M + 8 u |o| of slack)
+__device__ __forceinline__ bool slab_rel(const float* r, float ix, float iy, float iz, float t_min, float t_max, float& t_near) {
+    float ax = r[0] * ix, bx = r[3] * ix;
+    float ay = r[1] * iy, by = r[4] * iy;
+    float az = r[2] * iz, bz = r[5] * iz;
+    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), t_min));
+    float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), t_max));
     t_near = tn;
     return tn <= tf;
 }
@@ -353,7 +397,12 @@ __global__ void k_build_eye_tables(Scene sc, EyeNode* nodes, EyeTri* tris) {
         float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
         const float b[12] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w};
         const double oo[3] = {o.x, o.y, o.z};
-        for (int k = 0; k < 12; ++k) nodes[i].rel[k] = (double)b[k] - oo[k % 3];
+        const double E = fmax(fmax(fabs(o.x), fabs(o.y)), fabs(o.z)) * 0x1p-21;
+        for (int k = 0; k < 12; ++k) {
+            const bool is_lo = (k % 6) < 3;  // lo xyz, hi xyz per child
+            const double rel = (double)b[k] - oo[k % 3];  // exact to ~1e-16: f32 box plane minus f64 eye
+            nodes[i].rel[k] = is_lo ? f32_down(rel - E) : f32_up(rel + E);
+        }
         nodes[i].child[0] = __float_as_int(n3.x);
         nodes[i].child[1] = __float_as_int(n3.y);
         nodes[i].pad[0] = nodes[i].pad[1] = 0;
@@ -376,16 +425,18 @@ __device__ __forceinline__ uint32_t traverse_eye(const Scene& sc, D3 d, double t
     uint32_t best = PT_MISS, best_id = PT_MISS;
     if (sc.n_prims) prims_closest(sc, ld3(sc.cam.eye), d, t_min, t_max, best, best_id);
     if (sc.n_nodes == 0) return best;
-    D3 inv = mk(1. / d.x, 1. / d.y, 1. / d.z);
+    const float ix = (float)(1. / d.x), iy = (float)(1. / d.y), iz = (float)(1. / d.z);
+    const float t_min32 = f32_down(t_min);
+    float t_max32 = f32_up(t_max);
     int sp = 0;
     int cur = 0;
     while (cur != kDone) {
         while (cur >= 0) {
             const EyeNode& n = sc.eye_nodes[cur];
             int c0 = n.child[0], c1 = n.child[1];
-            double tn0, tn1;
-            bool h0 = slab_rel(n.rel, inv, t_min, t_max, tn0) && c0 != PT_BVH_EMPTY;
-            bool h1 = slab_rel(n.rel + 6, inv, t_min, t_max, tn1) && c1 != PT_BVH_EMPTY;
+            float tn0, tn1;
+            bool h0 = slab_rel(n.rel, ix, iy, iz, t_min32, t_max32, tn0) && c0 != PT_BVH_EMPTY;
+            bool h1 = slab_rel(n.rel + 6, ix, iy, iz, t_min32, t_max32, tn1) && c1 != PT_BVH_EMPTY;
             if (h0 && h1) {
                 int nearc = c0, farc = c1;
                 if (tn1 < tn0) { nearc = c1; farc = c0; }
@@ -408,6 +459,7 @@ __device__ __forceinline__ uint32_t traverse_eye(const Scene& sc, D3 d, double t
             uint32_t gid = e.gid;
             if (best != PT_MISS && !(t < t_max || gid < best_id)) continue;  // lowest id wins a tie, as in traverse()
             best = first + k; best_id = gid; t_max = t;
+            t_max32 = f32_up(t);
         }
         if (sp == 0) break;
         --sp;
