@@ -43,7 +43,7 @@ WORKLOADS = {
     "CornellBox": dict(scene="CornellBox", width=1920, height=1080, spp=1024, batch=64, label="BASELINE.json configs[1]"),
     "glossy_planes": dict(scene="glossy_planes", width=1920, height=1080, spp=256, batch=64, label="BASELINE.json configs[2]"),
     "Test_textured": dict(scene="Test", textures=True, width=3840, height=2160, spp=64, batch=16, label="BASELINE.json configs[3]"),
-    "heightfield": dict(scene="heightfield", width=3840, height=2160, spp=4096, batch=16, label="BASELINE.json configs[4]"),
+    "heightfield": dict(scene="heightfield", width=3840, height=2160, spp=4096, batch=32, label="BASELINE.json configs[4]"),
 }
 
 
@@ -141,7 +141,7 @@ class Workload:
         #               read-modify-write)
         # The scene terms 32 V + 36 T are HBM bytes of the traversing kernel only when the scene does
         # not fit one XCD's L2 (config 5); for a cache-resident scene they are reported as L2/LDS-served.
-        scene_bytes = data.n_tris * 48 + len(scene.bvh()[0]) * 64
+        scene_bytes = st["scene_bytes"]
         resident = scene_bytes < (4 << 20)  # one XCD's L2
         scene_ray = 32.0 * V + 36.0 * T
         rec, hit = 76.0, 12.0
@@ -214,7 +214,7 @@ class Workload:
             "kernel": dom, "avg_launch_ms": round(avg_ms, 4), "launches": launches,
             "hbm": hbm if (resident and valu) else None, "valu": valu if not resident else None,
             "pmc": {k: pmc.get(k) for k in ("valu_busy", "lane_utilisation", "waves_per_simd", "l2_hit", "clock_ghz")} if pmc else None,
-            "scene_cache_resident": resident, "scene_bytes": scene_bytes,
+            "scene_cache_resident": resident, "scene_bytes": scene_bytes, "tree_width": st["tree_width"], "stack_need": st["stack_need"],
             "l2_served_GBs": round(gbs(l2_bytes / launches, avg_ms), 2),
             "nodes_per_ray": round(V, 3), "tris_per_ray": round(T, 3),
             "nodes_per_primary_ray": round(V0, 3), "tris_per_primary_ray": round(T0, 3),

@@ -209,6 +209,9 @@ typedef struct pt_stats {
     pt_kernel_stat kernel[PT_K_COUNT];
     uint64_t lit_samples;    /* samples that gathered any radiance (the others are never stored or read:
                               * DESIGN.md "sparse radiance"); only with pt_set_profiling(..,2) */
+    uint64_t scene_bytes;    /* device bytes of the tree and the triangles the traversal reads */
+    uint32_t tree_width;     /* children per node of the device tree: 2 (depth <= 8) or 4 (deeper: collapsed) */
+    uint32_t stack_need;     /* traversal stack entries the deepest path of the device tree needs */
 } pt_stats;
 
 typedef struct pt_scene pt_scene;

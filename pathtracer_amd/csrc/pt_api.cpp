@@ -158,7 +158,10 @@ struct pt_scene {
     std::vector<uint32_t> order;
     uint32_t depth = 0;
     ptd::Scene dev{};
-    DevBuf d_nodes, d_tris, d_uvs, d_leaf_of, d_mats, d_texs, d_lights, d_emissive, d_prims, d_tri_shade, d_eye_nodes, d_eye_tris, d_ctr;
+    std::vector<pt_bvh_node4> nodes4;  // deep trees: the four-wide device tree
+    uint32_t stack_need = 0;           // entries the deepest path of the device tree needs
+    DevBuf d_nodes4;
+    DevBuf d_nodes, d_tris, d_uvs, d_leaf_of, d_mats, d_texs, d_lights, d_emissive, d_prims, d_tri_shade, d_tri_basis, d_eye_nodes, d_eye_tris, d_ctr;
     std::vector<DevBuf*> d_texels;
     Workspace ws;
     std::mutex mu;
@@ -216,7 +219,7 @@ void resolve_scheduling(ptd::Scene& dv) {
     dv.vote_shadow = flag("PT_TRAV_VOTE_SHADOW", deep);
     dv.fuse = flag("PT_FUSE", true);
     dv.fuse_shadow = flag("PT_FUSE_SHADOW", true) && dv.fuse;
-    dv.wave_rays = 256;
+    dv.wave_rays = 512;  // (128 / 256 / 512 / 1024 -> 8.73 / 9.17 / 9.29 / 9.3 Gsamples/s on the 10 M-triangle scene)
     if (const char* e = getenv("PT_WAVE_RAYS")) {
         uint32_t r = (uint32_t)atoi(e);
         if (r >= 64 && r <= ptd::kSegAlign && (r & (r - 1)) == 0) dv.wave_rays = r;
@@ -476,7 +479,14 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
         if (d->tri_uvs) std::memcpy(&uv6[(size_t)leaf * 6], d->tri_uvs + (size_t)g * 6, 6 * sizeof(float));
     }
     int rc;
-    if ((rc = upload(s->d_nodes, s->nodes.data(), s->nodes.size())) != PT_OK) return rc;
+    if (s->depth > 8) {  // deep: the kernels walk four-wide nodes (pt_bvh.cpp bvh_collapse4)
+        rc = pth::bvh_collapse4(s->nodes, (uint32_t)ptd::kWideStack, s->nodes4, s->stack_need);
+        if (rc != PT_OK) { set_error("four-wide collapse failed: stack need %u > %d", s->stack_need, ptd::kWideStack); return rc; }
+        if ((rc = upload(s->d_nodes4, s->nodes4.data(), s->nodes4.size())) != PT_OK) return rc;
+    } else {
+        s->stack_need = s->depth;
+        if ((rc = upload(s->d_nodes, s->nodes.data(), s->nodes.size())) != PT_OK) return rc;
+    }
     if ((rc = upload(s->d_tris, tri4.data(), tri4.size())) != PT_OK) return rc;
     if ((rc = upload(s->d_leaf_of, leaf_of.data(), leaf_of.size())) != PT_OK) return rc;
     if (d->tri_uvs && (rc = upload(s->d_uvs, uv6.data(), uv6.size())) != PT_OK) return rc;
@@ -580,7 +590,8 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
     HIP_TRY(hipEventCreateWithFlags(&s->ws_free, hipEventDisableTiming));
 
     ptd::Scene& dv = s->dev;
-    dv.nodes = s->d_nodes.as<float4>();
+    dv.nodes = s->d_nodes.as<float4>();    // null for a deep tree
+    dv.nodes4 = s->d_nodes4.as<float4>();  // null for a shallow one
     dv.tris = s->d_tris.as<float4>();
     dv.uvs = d->tri_uvs ? s->d_uvs.as<float2>() : nullptr;
     dv.leaf_of = s->d_leaf_of.as<uint32_t>();
@@ -630,13 +641,18 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
     dv.n_tris = d->n_tris;
     HIP_TRY(s->d_tri_shade.alloc(std::max<size_t>(d->n_tris, 1) * sizeof(ptd::TriShade)));
     dv.tri_shade = s->d_tri_shade.as<ptd::TriShade>();
-    ptd::launch_build_tri_shade(dv, s->d_tri_shade.as<ptd::TriShade>(), nullptr);
+    dv.tri_basis = nullptr;
+    if (d->n_tris && d->n_tris <= ptd::kEyeTableMaxTris) {
+        HIP_TRY(s->d_tri_basis.alloc((size_t)d->n_tris * sizeof(ptd::TriBasis)));
+        dv.tri_basis = s->d_tri_basis.as<ptd::TriBasis>();
+    }
+    ptd::launch_build_tri_shade(dv, s->d_tri_shade.as<ptd::TriShade>(), s->d_tri_basis.as<ptd::TriBasis>(), nullptr);
     ptd::launch_build_emitters(dv, d_emissive_leaf.as<uint32_t>(), dv.n_emissive, s->d_emissive.as<ptd::EmitTri>(), nullptr);
     HIP_TRY(hipDeviceSynchronize());  // d_emissive_leaf goes out of scope with this function
     dv.eye_nodes = nullptr;
     dv.eye_tris = nullptr;
     const char* eye_env = getenv("PT_EYE_TABLES");
-    if (dv.n_nodes && d->n_tris <= ptd::kEyeTableMaxTris && !(eye_env && atoi(eye_env) == 0)) {
+    if (dv.n_nodes && s->depth <= 8 && d->n_tris <= ptd::kEyeTableMaxTris && !(eye_env && atoi(eye_env) == 0)) {
         HIP_TRY(s->d_eye_nodes.alloc(s->nodes.size() * sizeof(ptd::EyeNode)));
         HIP_TRY(s->d_eye_tris.alloc((size_t)d->n_tris * sizeof(ptd::EyeTri)));
         ptd::launch_build_eye_tables(dv, s->d_eye_nodes.as<ptd::EyeNode>(), s->d_eye_tris.as<ptd::EyeTri>(), nullptr);
@@ -706,6 +722,9 @@ int pt_get_stats(pt_scene* s, pt_stats* out) {
     s->stats.nodes_visited = c.nodes;
     s->stats.tris_tested = c.tris;
     s->stats.lit_samples = c.lit;
+    s->stats.scene_bytes = (uint64_t)s->n_tris * 48 + (s->nodes4.empty() ? s->nodes.size() * sizeof(pt_bvh_node) : s->nodes4.size() * sizeof(pt_bvh_node4));
+    s->stats.tree_width = s->nodes4.empty() ? 2u : 4u;
+    s->stats.stack_need = s->stack_need;
     *out = s->stats;
     return PT_OK;
 }
@@ -942,10 +961,11 @@ int pt_render_device(pt_scene* s, const pt_render_params* P_in, double* accum_de
                        P->max_bounces > 0;
     // Frames in flight per pass.  Every launch ends in a tail that does not shrink with the batch (the
     // longest rays of the 10M-triangle scene take ~0.4 ms on their own; measured 0.30 + 0.47 ms per
-    // frame for its primary kernel at 4K), so batches are large: ~128M paths by default (~26 GB of
-    // queues out of 288), halved while the allocation does not fit.
+    // frame for its primary kernel at 4K), so batches are large: ~256M paths by default (~52 GB of
+    // queues out of 288; 16 / 32 / 64 frames at 4K -> 9.17 / 9.43 / 9.65 Gsamples/s on that scene), halved
+    // while the allocation does not fit.
     uint32_t spp = P->spp_per_batch;
-    if (spp == 0) spp = std::max<uint32_t>(1u, (1u << 27) / npix);
+    if (spp == 0) spp = std::max<uint32_t>(1u, (1u << 28) / npix);
     spp = std::min(spp, P->sample_count);
     spp = std::min<uint32_t>(spp, std::max<uint32_t>(1u, (1u << 30) / npix));
     // All renders of a scene share its workspace (queues, hit records, counters, per-sample radiance,

@@ -428,6 +428,121 @@ void bvh_widen(std::vector<pt_bvh_node>& nodes, const float* verts, uint32_t n_v
         }
 }
 
+// ---- four-wide nodes for deep trees ------------------------------------------------------------------
+// A ray in a deep tree is a chain of dependent node fetches, each a trip to L2 / HBM.  Collapsing the
+// validated two-child tree into nodes of up to four children halves that chain: a node absorbs the
+// inner child with the largest box (by half-area) until it has four children.  Leaf references and
+// boxes are taken over unchanged, so a ray opens the same leaves.
+//
+// Stack bound.  Descending into one of k children leaves k - 1 on the stack, so the traversal needs
+// max over root-to-leaf paths of sum(k_i - 1) entries.  The kernels hold `budget` entries (16 in LDS +
+// 48 in private memory) and the collapse makes that bound a property of the tree: a child subtree of
+// two-child height h can always be emitted as it is with h entries, so a node may grow to k children
+// only while every child's height fits the entries left, h(child) <= b - (k - 1); the children then
+// inherit b - (k - 1).  By induction every subtree needs at most its b; the root's is `budget` and
+// bvh_validate has bounded the height by 32.  The actual need is returned for the statistics.
+int bvh_collapse4(const std::vector<pt_bvh_node>& nodes2, uint32_t budget, std::vector<pt_bvh_node4>& out, uint32_t& need_out) {
+    out.clear();
+    need_out = 0;
+    if (nodes2.empty()) return PT_OK;
+    const size_t n2 = nodes2.size();
+    // two-child height of every inner node (leaves 0), by an explicit post-order walk
+    std::vector<uint8_t> h2(n2, 0);
+    {
+        std::vector<std::pair<int, int>> st;  // (node, next child to visit)
+        st.push_back({0, 0});
+        while (!st.empty()) {
+            auto& [i, c] = st.back();
+            if (c < 2) {
+                int32_t ch = nodes2[i].child[c++];
+                if (ch >= 0 && ch != PT_BVH_EMPTY) st.push_back({ch, 0});
+            } else {
+                uint8_t h = 0;
+                for (int k = 0; k < 2; ++k) {
+                    int32_t ch = nodes2[i].child[k];
+                    if (ch >= 0 && ch != PT_BVH_EMPTY) h = std::max(h, h2[ch]);
+                }
+                h2[i] = (uint8_t)(h + 1);
+                st.pop_back();
+            }
+        }
+    }
+    if (h2[0] > budget) return PT_ERR_UNSUPPORTED;
+    struct Kid { int32_t ref; float lo[3], hi[3]; };
+    auto height = [&](int32_t ref) -> uint32_t { return (ref >= 0 && ref != PT_BVH_EMPTY) ? h2[ref] : 0u; };
+    auto area = [](const Kid& k) {
+        float dx = k.hi[0] - k.lo[0], dy = k.hi[1] - k.lo[1], dz = k.hi[2] - k.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    auto kids_of = [&](int32_t node, Kid* dst) {
+        int n = 0;
+        for (int c = 0; c < 2; ++c) {
+            if (nodes2[node].child[c] == PT_BVH_EMPTY) continue;
+            Kid& k = dst[n++];
+            k.ref = nodes2[node].child[c];
+            for (int a = 0; a < 3; ++a) { k.lo[a] = nodes2[node].bounds[c * 6 + a]; k.hi[a] = nodes2[node].bounds[c * 6 + 3 + a]; }
+        }
+        return n;
+    };
+    struct Item { int32_t node2; uint32_t out; uint32_t b; };
+    std::vector<Item> work;
+    out.reserve(n2 / 2 + 16);
+    out.emplace_back();
+    work.push_back({0, 0u, budget});
+    std::vector<uint32_t> need(1, 0);  // filled bottom-up afterwards
+    std::vector<int32_t> parent(1, -1);
+    while (!work.empty()) {
+        Item it = work.back();
+        work.pop_back();
+        Kid kid[4];
+        int k = kids_of(it.node2, kid);
+        while (k < 4) {
+            int best = -1;
+            for (int c = 0; c < k; ++c) {
+                if (kid[c].ref < 0 || kid[c].ref == PT_BVH_EMPTY) continue;  // a leaf stays
+                if (best < 0 || area(kid[c]) > area(kid[best])) best = c;
+            }
+            if (best < 0) break;
+            Kid two[2];
+            int n_new = kids_of(kid[best].ref, two);
+            const int k_new = k - 1 + n_new;
+            if (k_new > 4) break;
+            // every child of the grown node must still fit the entries left below it
+            bool fits = (uint32_t)(k_new - 1) <= it.b;
+            const uint32_t left = it.b - (uint32_t)(k_new - 1);
+            for (int c = 0; c < k && fits; ++c) if (c != best && height(kid[c].ref) > left) fits = false;
+            for (int c = 0; c < n_new && fits; ++c) if (height(two[c].ref) > left) fits = false;
+            if (!fits) break;
+            kid[best] = two[0];
+            if (n_new == 2) kid[k++] = two[1];
+        }
+        pt_bvh_node4 n4;
+        std::memset(&n4, 0, sizeof n4);
+        for (int c = 0; c < 4; ++c) {
+            n4.child[c] = PT_BVH_EMPTY;
+            if (c >= k) continue;
+            for (int a = 0; a < 3; ++a) { n4.lo[a][c] = kid[c].lo[a]; n4.hi[a][c] = kid[c].hi[a]; }
+            if (kid[c].ref < 0) { n4.child[c] = kid[c].ref; continue; }
+            const uint32_t idx = (uint32_t)out.size();
+            out.emplace_back();
+            parent.push_back((int32_t)it.out);
+            n4.child[c] = (int32_t)idx;
+            work.push_back({kid[c].ref, idx, it.b - (uint32_t)(k - 1)});
+        }
+        n4.count = (uint32_t)k;
+        out[it.out] = n4;
+    }
+    // actual stack need: children have larger indices than their parent
+    need.assign(out.size(), 0);
+    for (size_t i = out.size(); i-- > 0;) {
+        uint32_t below = 0;
+        for (int c = 0; c < 4; ++c) if (out[i].child[c] >= 0 && out[i].child[c] != PT_BVH_EMPTY) below = std::max(below, need[out[i].child[c]]);
+        need[i] = (out[i].count ? out[i].count - 1 : 0) + below;
+    }
+    need_out = need[0];
+    return need_out <= budget ? PT_OK : PT_ERR_UNSUPPORTED;
+}
+
 // Walks a BVH (the library's or a caller's) and checks everything the extend kernel assumes:
 // child indices in range, no cycles (each inner node reached once), leaf runs inside
 // [0, n_tris), every triangle referenced exactly once, depth within the LDS stack.

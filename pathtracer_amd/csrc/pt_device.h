@@ -54,6 +54,14 @@ struct TriShade {
     uint32_t mat;
     uint32_t pad;
 };
+// The orthonormal basis Vec3::rotate_to (vec3.rs:154-166) builds around that normal, which every BRDF
+// sample at the triangle would otherwise rebuild (a division and ~20 f64 operations): rotate_to(v, n) =
+// t1 v.x + t2 v.y + n v.z.  Built by the expressions of rotate_to itself, so the sampled direction has the
+// same bits.  Only for scenes of up to kEyeTableMaxTris triangles: for a large scene the 48-byte gather per
+// shaded hit costs more than the arithmetic.
+struct TriBasis {
+    double t1[3], t2[3];
+};
 
 // Primary rays all start at the eye, so everything in the slab and triangle tests that depends on
 // the origin but not on the direction is the same for every one of them: child boxes relative to
@@ -104,10 +112,12 @@ struct Light {  // one emissive triangle, or (sphere != 0) an emissive sphere: v
 };
 
 struct Scene {
-    const float4* nodes;
+    const float4* nodes;   // two-child nodes (pt_bvh_node): the tree of a shallow scene (depth <= 8)
+    const float4* nodes4;  // four-wide nodes (pt_bvh_node4, 8 x float4 each): the tree of a deep scene
     const float4* tris;
     const float2* uvs;
     const TriShade* tri_shade;  // [n_tris], leaf order
+    const TriBasis* tri_basis;  // [n_tris], leaf order, or nullptr (large scenes)
     const EyeNode* eye_nodes;   // primary-ray tables (nullptr: not built for this scene)
     const EyeTri* eye_tris;
     const uint32_t* leaf_of;  // global triangle id -> leaf-order index
@@ -269,7 +279,12 @@ struct Counters {  // device-side statistics (pt_stats)
     unsigned long long rays, shadow_rays, nodes, tris, lit;
 };
 
-constexpr int kStackDepth = 32;  // LDS traversal stack entries per lane; builder bounds tree depth
+constexpr int kStackDepth = 32;  // deepest two-child tree accepted (bvh_validate); the builder stays below it
+// Traversal stacks.  A shallow tree (depth <= 8) is walked as it is with 8 LDS entries per lane.  A deeper
+// one is collapsed to four-wide nodes (pt_bvh.cpp bvh_collapse4), whose stack need the collapse bounds by
+// kWideStack = kWideLds entries in LDS + kWideSpill in private memory (touched only by the rare ray that
+// goes beyond 16).
+constexpr int kWideLds = 16, kWideSpill = 48, kWideStack = kWideLds + kWideSpill;
 constexpr int kBlock = 256;
 constexpr int kTravBlock = 64;  // extend / shadow: one wave per workgroup, LDS and registers are released per wave
 
@@ -296,7 +311,7 @@ void launch_accumulate(const Frame& fr, Sample3 lsample, const unsigned long lon
                        Counters* ctr /* nullptr: no statistics */, hipStream_t st);
 // parity entry points
 void launch_build_eye_tables(const Scene& sc, EyeNode* nodes, EyeTri* tris, hipStream_t st);
-void launch_build_tri_shade(const Scene& sc, TriShade* out, hipStream_t st);
+void launch_build_tri_shade(const Scene& sc, TriShade* out, TriBasis* basis /* or nullptr */, hipStream_t st);
 void launch_build_emitters(const Scene& sc, const uint32_t* leaf, uint32_t n, EmitTri* out, hipStream_t st);
 void launch_leaf_to_global(const Scene& sc, uint32_t* tri, uint32_t n, hipStream_t st);
 void launch_sample_brdf(const Scene& sc, const Frame& fr, uint32_t bounce, const double* rays /* pt_ray[n] */,

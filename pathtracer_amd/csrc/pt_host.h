@@ -7,6 +7,18 @@
 
 #include "../../include/pt.h"
 
+// Four-wide node of the device tree of a deep scene (pt_bvh.cpp bvh_collapse4): the boxes of up to four
+// children, one float4 per plane (lane k of each = child k), their references (as pt_bvh_node::child)
+// and how many there are.  128 bytes = eight 16-byte loads.
+struct pt_bvh_node4 {
+    float lo[3][4];
+    float hi[3][4];
+    int32_t child[4];
+    uint32_t count;
+    uint32_t pad[3];
+};
+static_assert(sizeof(pt_bvh_node4) == 128, "device layout");
+
 namespace pth {
 
 // thread-local error text behind pt_last_error()
@@ -16,6 +28,7 @@ const char* last_error();
 // pt_bvh.cpp
 int bvh_build(const float* verts, uint32_t n_verts, const uint32_t* tris, uint32_t n_tris, uint32_t max_leaf,
               std::vector<pt_bvh_node>& out_nodes, std::vector<uint32_t>& out_order, uint32_t& out_depth);
+int bvh_collapse4(const std::vector<pt_bvh_node>& nodes2, uint32_t budget, std::vector<pt_bvh_node4>& out, uint32_t& need_out);
 void bvh_widen(std::vector<pt_bvh_node>& nodes, const float* verts, uint32_t n_verts);
 int bvh_validate(const pt_bvh_node* nodes, uint32_t n_nodes, const uint32_t* order, uint32_t n_tris,
                  uint32_t stack_depth, uint32_t& depth_out, std::string& why);

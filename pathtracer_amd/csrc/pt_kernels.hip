@@ -109,8 +109,8 @@ void launch_generate_rays(const Scene& sc, const Frame& fr, double* rays_out, hi
     if (!fr.n_tile_pixels) return;
     hipLaunchKernelGGL(k_generate_rays, dim3(blocks_for(fr.n_tile_pixels)), dim3(kBlock), 0, st, sc, fr, rays_out);
 }
-// The LDS stack is sized for the scene's BVH depth: 8 / 16 / 32 entries per lane (8 / 16 / 32 KB per
-// block), so shallow trees do not pay occupancy for stack they cannot use.
+// Two traversal forms, by the scene's tree depth (pt_device.h "Traversal stacks"): the two-child tree with
+// an 8-entry LDS stack up to depth 8, the four-wide tree with 16 LDS entries + private spill beyond.
 // workgroups of a persistent launch: enough one-wave workgroups to fill every SIMD at the occupancy
 // the traversal kernels reach (<= 6 waves), whatever the queue holds
 static uint32_t persistent_blocks(const Scene& sc) {
@@ -123,8 +123,7 @@ static void launch_extend_v(const Scene& sc, const Frame& fr, Queue q, const dou
     dim3 g(live.counts ? (live.n + br - 1) / br : trav_blocks(live.n, br)), b(kTravBlock);
     if (VOTE && live.cursors) g.x = min(g.x, persistent_blocks(sc));
     if (sc.bvh_depth <= 8) hipLaunchKernelGGL((k_extend<8, STATS, PRIMARY, VOTE>), g, b, 0, st, sc, fr, q, tmin, tmax, live, wr, hits, ctr);
-    else if (sc.bvh_depth <= 16) hipLaunchKernelGGL((k_extend<16, STATS, PRIMARY, VOTE>), g, b, 0, st, sc, fr, q, tmin, tmax, live, wr, hits, ctr);
-    else hipLaunchKernelGGL((k_extend<32, STATS, PRIMARY, VOTE>), g, b, 0, st, sc, fr, q, tmin, tmax, live, wr, hits, ctr);
+    else hipLaunchKernelGGL((k_extend<kWideLds, STATS, PRIMARY, VOTE>), g, b, 0, st, sc, fr, q, tmin, tmax, live, wr, hits, ctr);
 }
 template <bool STATS, bool PRIMARY>
 static void launch_extend_t(const Scene& sc, const Frame& fr, Queue q, const double* tmin, const double* tmax, Live live,
@@ -220,7 +219,7 @@ bool launch_path(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, Li
     bool first = bounce == 0, last = bounce >= fr.max_bounces;
     // the variant launch_path_t picks: the scene-in-LDS kernel has its own workgroup size
     const bool lds = sc.bvh_depth <= 8 && !last && sc.lds_scene;
-    const uint32_t kPathBlock = lds ? PathBlock<8, true>::value : (sc.bvh_depth <= 8 ? PathBlock<8>::value : PathBlock<32>::value);
+    const uint32_t kPathBlock = lds ? PathBlock<8, true>::value : (sc.bvh_depth <= 8 ? PathBlock<8>::value : PathBlock<kWideLds>::value);
     dim3 g(live.counts ? (live.n + kPathBlock - 1) / kPathBlock : trav_blocks(live.n, kPathBlock)), b(kPathBlock);
     if (last && !first && live.counts && sc.cull_last) {  // the queue after the cull: a few percent full
         live.sparse = 1;
@@ -232,10 +231,8 @@ bool launch_path(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, Li
         else if (first) PT_PATH(8, true, false);
         else if (last) PT_PATH(8, false, true);
         else PT_PATH(8, false, false);
-    } else if (sc.bvh_depth <= 16) {  // deeper trees: primary bounce only (path_fusable)
-        if (last) PT_PATH(16, true, true); else PT_PATH(16, true, false);
-    } else {
-        if (last) PT_PATH(32, true, true); else PT_PATH(32, true, false);
+    } else {  // deeper trees: primary bounce only (path_fusable)
+        if (last) PT_PATH(kWideLds, true, true); else PT_PATH(kWideLds, true, false);
     }
     #undef PT_PATH
     return true;
@@ -246,8 +243,7 @@ static void launch_shadow_v(const Scene& sc, ShadowQueue sq, Live live, uint32_t
     dim3 g((live.n + br - 1) / br), b(kTravBlock);
     if (VOTE && live.cursors) g.x = min(g.x, persistent_blocks(sc));
     if (sc.bvh_depth <= 8) hipLaunchKernelGGL((k_shadow<8, VOTE>), g, b, 0, st, sc, sq, live, wr, ls, ctr);
-    else if (sc.bvh_depth <= 16) hipLaunchKernelGGL((k_shadow<16, VOTE>), g, b, 0, st, sc, sq, live, wr, ls, ctr);
-    else hipLaunchKernelGGL((k_shadow<32, VOTE>), g, b, 0, st, sc, sq, live, wr, ls, ctr);
+    else hipLaunchKernelGGL((k_shadow<kWideLds, VOTE>), g, b, 0, st, sc, sq, live, wr, ls, ctr);
 }
 void launch_shadow(const Scene& sc, ShadowQueue sq, Live live, Sample3 ls, Counters* ctr, hipStream_t st) {
     if (!live.n) return;
@@ -277,9 +273,9 @@ void launch_build_emitters(const Scene& sc, const uint32_t* leaf, uint32_t n, Em
     if (!n) return;
     hipLaunchKernelGGL(k_build_emitters, dim3(blocks_for(n)), dim3(kBlock), 0, st, sc, leaf, n, out);
 }
-void launch_build_tri_shade(const Scene& sc, TriShade* out, hipStream_t st) {
+void launch_build_tri_shade(const Scene& sc, TriShade* out, TriBasis* basis, hipStream_t st) {
     if (!sc.n_tris) return;
-    hipLaunchKernelGGL(k_build_tri_shade, dim3(blocks_for(sc.n_tris)), dim3(kBlock), 0, st, sc, out);
+    hipLaunchKernelGGL(k_build_tri_shade, dim3(blocks_for(sc.n_tris)), dim3(kBlock), 0, st, sc, out, basis);
 }
 void launch_leaf_to_global(const Scene& sc, uint32_t* tri, uint32_t n, hipStream_t st) {
     if (!n) return;

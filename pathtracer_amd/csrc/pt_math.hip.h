@@ -31,13 +31,19 @@ __device__ __forceinline__ D3 normalize(D3 a) { return a / length(a); }  // vec3
 __device__ __forceinline__ double comp(D3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 // vec3.rs:138-140 (normalises)
 __device__ __forceinline__ D3 reflect(D3 self, D3 other) { return normalize(self - 2. * dot(self, other) * other); }
-// vec3.rs:154-166
-__device__ __forceinline__ D3 rotate_to(D3 self, D3 n) {
+// vec3.rs:154-166: rotate_to(self, n) = t1 self.x + t2 self.y + n self.z, (t1, t2) the Frisvad / Duff basis of n
+__device__ __forceinline__ void rotate_basis(D3 n, D3& t1, D3& t2) {
     double sign = (n.z != n.z) ? n.z : copysign(1.0, n.z);  // f64::signum
     double a = -1. / (1. + fabs(n.z));
     double b = n.x * n.y * a;
-    return mk(1. + n.x * n.x * a, b, -sign * n.x) * self.x + mk(sign * b, sign * (1. + n.y * n.y * a), -n.y) * self.y +
-           n * self.z;
+    t1 = mk(1. + n.x * n.x * a, b, -sign * n.x);
+    t2 = mk(sign * b, sign * (1. + n.y * n.y * a), -n.y);
+}
+__device__ __forceinline__ D3 rotate_with(D3 self, D3 t1, D3 t2, D3 n) { return t1 * self.x + t2 * self.y + n * self.z; }
+__device__ __forceinline__ D3 rotate_to(D3 self, D3 n) {
+    D3 t1, t2;
+    rotate_basis(n, t1, t2);
+    return rotate_with(self, t1, t2, n);
 }
 
 #define PT_PI 3.14159265358979323846264338327950288

@@ -315,6 +315,17 @@ __device__ __forceinline__ Brdf lambertian_sample(D3 color, D3 n, double xi1, do
     D3 wi = rotate_to(mk(sin_theta * cp, sin_theta * sp, cos_theta), n);
     return {color * PT_FRAC_1_PI, wi, dot(n, wi) * PT_FRAC_1_PI};
 }
+// The direction alone (material.rs:9-23), with the basis of the normal given (TriBasis) or built here.
+__device__ __forceinline__ D3 lambertian_dir(D3 n, const TriBasis* basis, double xi1, double xi2) {
+    double cos_theta = sqrt(xi1);
+    double sin_theta = sqrt(1.0 - xi1);
+    double phi = 2.0 * PT_PI * xi2;
+    double sp, cp;
+    sincos(phi, &sp, &cp);
+    const D3 local = mk(sin_theta * cp, sin_theta * sp, cos_theta);
+    if (basis) return rotate_with(local, ld3(basis->t1), ld3(basis->t2), n);
+    return rotate_to(local, n);
+}
 // microfacet.rs:52-62 + 147-159
 __device__ Brdf glossy_sample(double width, D3 reflectance, D3 ray_dir, D3 n, double xi1, double xi2, bool ggx) {
     D3 wo = -ray_dir;
@@ -348,13 +359,19 @@ struct ShadePoint {
 };
 // triangle_mesh.rs:141: normal = -(e0 x e1).normalize(), e0 = v1 - v0, e1 = v0 - v2
 __device__ __forceinline__ D3 tri_unit_normal(const TriV& tr) { return -normalize(cross(tr.v1 - tr.v0, tr.v0 - tr.v2)); }
-__global__ void k_build_tri_shade(Scene sc, TriShade* out) {
+__global__ void k_build_tri_shade(Scene sc, TriShade* out, TriBasis* basis) {
     uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
     if (leaf >= sc.n_tris) return;
     D3 n = tri_unit_normal(load_tri(sc, leaf));
     out[leaf].n[0] = n.x; out[leaf].n[1] = n.y; out[leaf].n[2] = n.z;
     out[leaf].mat = (uint32_t)__float_as_int(sc.tris[(size_t)leaf * 3 + 1].w);
     out[leaf].pad = 0;
+    if (basis) {
+        D3 t1, t2;
+        rotate_basis(n, t1, t2);
+        basis[leaf].t1[0] = t1.x; basis[leaf].t1[1] = t1.y; basis[leaf].t1[2] = t1.z;
+        basis[leaf].t2[0] = t2.x; basis[leaf].t2[1] = t2.y; basis[leaf].t2[2] = t2.z;
+    }
 }
 __device__ __forceinline__ uint32_t hit_material(const Scene& sc, uint32_t leaf) {
     return leaf >= PT_PRIM_BASE ? sc.prims[leaf - PT_PRIM_BASE].mat : sc.tri_shade[leaf].mat;
@@ -640,12 +657,22 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
                     r.n_T = T;  // specular: radiance passes unchanged
                     r.n_d = specular_sample(m, d, normal, xi1, lobe);
                     r.n_pdf = -1.;
-                } else {
-                    Brdf bs = (SPEC && is_glossy(m.kind)) ? glossy_sample(m.width, ld3(m.color), d, normal, xi1, xi2, m.kind == PT_MAT_GLOSSY_GGX)
-                                                      : lambertian_sample(diffuse, normal, xi1, xi2);
+                } else if (SPEC && is_glossy(m.kind)) {
+                    Brdf bs = glossy_sample(m.width, ld3(m.color), d, normal, xi1, xi2, m.kind == PT_MAT_GLOSSY_GGX);
                     r.n_T = T * (bs.f * fabs(dot(bs.wi, normal)) / bs.pdf);  // main.rs:311
                     r.n_d = bs.wi;
                     r.n_pdf = bs.pdf > 0. ? bs.pdf : 0.;
+                } else {
+                    // Lambertian (material.rs:37-58): f = rho / pi, pdf = (n . wi) / pi, so main.rs:311's
+                    // f |wi . n| / pdf is rho; the closed form is used (within 4 ulp of the quotient; they part
+                    // only where xi1 < 2^-52 puts wi in the tangent plane and the quotient is -rho or NaN)
+                    const TriBasis* basis = (sc.tri_basis && leaf < PT_PRIM_BASE) ? sc.tri_basis + leaf : nullptr;
+                    r.n_d = lambertian_dir(normal, basis, xi1, xi2);
+                    r.n_T = T * diffuse;
+                    if (NEE) {  // the pdf feeds only the MIS weight of the next vertex
+                        const double pdf = dot(normal, r.n_d) * PT_FRAC_1_PI;
+                        r.n_pdf = pdf > 0. ? pdf : 0.;
+                    }
                 }
                 if (luminance != 1.) r.n_T = r.n_T / luminance;
                 r.n_o = position;  // main.rs:314
@@ -777,15 +804,17 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value)) void k_path(Scene g
     __shared__ float4 s_nodes[LDS ? kLdsScene * 4 : 1];
     __shared__ float4 s_tris[LDS ? kLdsScene * 3 : 1];
     __shared__ float4 s_shade[LDS ? kLdsScene * 2 : 1];
+    __shared__ float4 s_basis[(LDS && !LAST) ? kLdsScene * 3 : 1];
     __shared__ double s_mats[LDS ? kLdsMats * kMatWords : 1];
     __shared__ float4 s_eye_nodes[(LDS && FIRST) ? kLdsScene * 4 : 1];
     __shared__ float4 s_eye_tris[(LDS && FIRST) ? kLdsScene * 7 : 1];
-    static_assert(sizeof(TriShade) == 32 && sizeof(EyeNode) == 64 && sizeof(EyeTri) == 112 && sizeof(Material) % 8 == 0, "LDS copies");
+    static_assert(sizeof(TriShade) == 32 && sizeof(TriBasis) == 48 && sizeof(EyeNode) == 64 && sizeof(EyeTri) == 112 && sizeof(Material) % 8 == 0, "LDS copies");
     Scene sc = gsc;
     if (LDS) {  // pointers first (compile-time: the address space is then known at every use), data below
         sc.nodes = s_nodes;
         sc.tris = s_tris;
         sc.tri_shade = reinterpret_cast<const TriShade*>(s_shade);
+        if (!LAST) sc.tri_basis = reinterpret_cast<const TriBasis*>(s_basis);  // (an LDS scene always has the table)
         sc.mats = reinterpret_cast<const Material*>(s_mats);
         if (FIRST) {
             sc.eye_nodes = reinterpret_cast<const EyeNode*>(s_eye_nodes);
@@ -822,6 +851,10 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value)) void k_path(Scene g
                 for (uint32_t k = threadIdx.x; k < gsc.n_tris * 3; k += kPathBlock) s_tris[k] = gsc.tris[k];
             }
             for (uint32_t k = threadIdx.x; k < gsc.n_tris * 2; k += kPathBlock) s_shade[k] = g_shade[k];
+            if (!LAST) {
+                const float4* g_basis = reinterpret_cast<const float4*>(gsc.tri_basis);
+                for (uint32_t k = threadIdx.x; k < gsc.n_tris * 3; k += kPathBlock) s_basis[k] = g_basis[k];
+            }
             for (uint32_t k = threadIdx.x; k < gsc.n_mats * kMatWords; k += kPathBlock) s_mats[k] = g_mats[k];
             if (FIRST) {
                 const float4* g_en = reinterpret_cast<const float4*>(gsc.eye_nodes);

@@ -88,10 +88,17 @@ __device__ __forceinline__ bool tri_test(const TriV& tr, D3 o, D3 d, double t_mi
 //     return the non-NaN operand and either outcome is then right.
 // A box opened without need costs time, never correctness.
 struct RayF {
-    float olx, oly, olz;  // fl(o + E): subtracted from the lo planes
-    float ohx, ohy, ohz;  // fl(o - E): subtracted from the hi planes
-    float ix, iy, iz;     // fl(1 / d)
+    float clx, cly, clz;  // fl(ol * i), ol = fl(o + E): subtracted from lo * i
+    float chx, chy, chz;  // fl(oh * i), oh = fl(o - E): subtracted from hi * i
+    float ix, iy, iz;     // i = fl(1 / d), magnitude capped at 2^100
 };
+// The plane distances are formed as fma(plane, i, -c), c = fl(origin * i): one instruction per plane.
+// Against the sub-then-mul form analysed above the error terms change from 3 u |lo - ol| / |d| to
+// (2 u |lo - ol| + u |ol|) / |d| (rounding of i and of the fma, and of c), still below the
+// (8 u M + 6.9 u |o|) / |d| of slack.  An infinite i would give inf - inf, so |i| is capped at 2^100: on an
+// axis with |d_k| < 2^-100 the computed slab is then [-s 2^100, +s 2^100] around the box, s >= 2^-21 M
+// its slack, instead of [-inf, inf], which still holds every hit with t <= 2^79 M - all of them unless
+// the whole direction vector is that tiny (|d| < 2^-60: such a ray opens every box, ix = NaN).
 __device__ __forceinline__ float f32_up(double x) {  // smallest f32 >= x (x not NaN)
     float f = (float)x;
     if ((double)f < x) f = f >= 0.f ? __uint_as_float(__float_as_uint(f) + 1u) : __uint_as_float(__float_as_uint(f) - 1u);
@@ -100,17 +107,27 @@ __device__ __forceinline__ float f32_up(double x) {  // smallest f32 >= x (x not
 __device__ __forceinline__ float f32_down(double x) { return -f32_up(-x); }
 __device__ __forceinline__ RayF make_rayf(D3 o, D3 d) {
     const double E = fmax(fmax(fabs(o.x), fabs(o.y)), fabs(o.z)) * 0x1p-21;
+    const float olx = (float)(o.x + E), oly = (float)(o.y + E), olz = (float)(o.z + E);
+    const float ohx = (float)(o.x - E), ohy = (float)(o.y - E), ohz = (float)(o.z - E);
     RayF r;
-    r.olx = (float)(o.x + E); r.oly = (float)(o.y + E); r.olz = (float)(o.z + E);
-    r.ohx = (float)(o.x - E); r.ohy = (float)(o.y - E); r.ohz = (float)(o.z - E);
-    r.ix = (float)(1. / d.x); r.iy = (float)(1. / d.y); r.iz = (float)(1. / d.z);
+    auto inv = [](double dk) { return copysignf(fminf(fabsf((float)(1. / dk)), 0x1p100f), (float)(1. / dk)); };
+    r.ix = inv(d.x); r.iy = inv(d.y); r.iz = inv(d.z);
+    if (!(fmax(fmax(fabs(d.x), fabs(d.y)), fabs(d.z)) >= 0x1p-60)) r.ix = r.iy = r.iz = __builtin_nanf("");  // no cull
+    r.clx = olx * r.ix; r.cly = oly * r.iy; r.clz = olz * r.iz;
+    r.chx = ohx * r.ix; r.chy = ohy * r.iy; r.chz = ohz * r.iz;
     return r;
 }
 __device__ __forceinline__ bool slab32(float lox, float loy, float loz, float hix, float hiy, float hiz, const RayF& r,
                                        float t_min, float t_max, float& t_near) {
-    float ax = (lox - r.olx) * r.ix, bx = (hix - r.ohx) * r.ix;
-    float ay = (loy - r.oly) * r.iy, by = (hiy - r.ohy) * r.iy;
-    float az = (loz - r.olz) * r.iz, bz = (hiz - r.ohz) * r.iz;
+#ifdef PT_SLAB_MULSUB  // (tuning builds: the product and the difference as two instructions)
+    float ax = lox * r.ix - r.clx, bx = hix * r.ix - r.chx;
+    float ay = loy * r.iy - r.cly, by = hiy * r.iy - r.chy;
+    float az = loz * r.iz - r.clz, bz = hiz * r.iz - r.chz;
+#else
+    float ax = __builtin_fmaf(lox, r.ix, -r.clx), bx = __builtin_fmaf(hix, r.ix, -r.chx);
+    float ay = __builtin_fmaf(loy, r.iy, -r.cly), by = __builtin_fmaf(hiy, r.iy, -r.chy);
+    float az = __builtin_fmaf(loz, r.iz, -r.clz), bz = __builtin_fmaf(hiz, r.iz, -r.chz);
+#endif
     float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), t_min));
     float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), t_max));
     t_near = tn;
@@ -199,6 +216,73 @@ __device__ __forceinline__ int node_step(const Scene& sc, int cur, const RayF& r
     return stk[sp * STRIDE];
 }
 
+// ---- four-wide nodes (deep trees) -----------------------------------------------------------------------
+// The stack of a wide traversal: kWideLds entries in LDS ([entry][lane], as above), the rest in a private
+// array that only a ray with more than kWideLds pending subtrees touches.  bvh_collapse4 bounds the need
+// by kWideStack for every tree that passed bvh_validate.
+struct WideStack {
+    int* lds;     // this lane's column: entry e at lds[e * STRIDE]
+    int* spill;   // kWideSpill private entries
+};
+template <int STRIDE>
+__device__ __forceinline__ void wide_push(const WideStack& st, int& sp, int ref) {
+    PT_STACK_CHECK(sp, kWideStack);
+    if (sp < kWideLds) st.lds[sp * STRIDE] = ref;
+    else if (sp < kWideStack) st.spill[sp - kWideLds] = ref;
+    ++sp;
+}
+template <int STRIDE>
+__device__ __forceinline__ int wide_pop(const WideStack& st, int& sp) {
+    if (sp == 0) return kDone;
+    --sp;
+    return sp < kWideLds ? st.lds[sp * STRIDE] : st.spill[sp - kWideLds];
+}
+// One step at a four-wide node: the four boxes are tested together (one float4 per plane), the children
+// that are hit are ordered by entry distance with a 5-comparator network on keys (distance bits with
+// the child's slot in the two low bits; a miss is the largest key), the nearest becomes the next node
+// and the others go on the stack, farthest first.
+template <bool STATS, int STRIDE>
+__device__ __forceinline__ int node4_step(const Scene& sc, int cur, const RayF& rf, float t_min, float t_max,
+                                          const WideStack& st, int& sp, uint32_t& n_nodes) {
+    const float4* np = sc.nodes4 + (size_t)cur * 8;
+    const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5];
+    const float4 cf = np[6];
+    const int c[4] = {__float_as_int(cf.x), __float_as_int(cf.y), __float_as_int(cf.z), __float_as_int(cf.w)};
+    const float lox[4] = {lx.x, lx.y, lx.z, lx.w}, loy[4] = {ly.x, ly.y, ly.z, ly.w}, loz[4] = {lz.x, lz.y, lz.z, lz.w};
+    const float hix[4] = {hx.x, hx.y, hx.z, hx.w}, hiy[4] = {hy.x, hy.y, hy.z, hy.w}, hiz[4] = {hz.x, hz.y, hz.z, hz.w};
+    uint32_t key[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float tn;
+        const bool hit = slab32(lox[k], loy[k], loz[k], hix[k], hiy[k], hiz[k], rf, t_min, t_max, tn) && c[k] != PT_BVH_EMPTY;
+        if (STATS) n_nodes += c[k] != PT_BVH_EMPTY;
+        // tn >= t_min; for the usual t_min >= 0 its bits order like unsigned integers (a negative t_min only
+        // perturbs the visiting order)
+        key[k] = hit ? ((__float_as_uint(tn) & ~3u) | (uint32_t)k) : 0xFFFFFFFFu;
+    }
+#define PT_CSWAP(a, b) { const uint32_t lo_ = min(key[a], key[b]), hi_ = max(key[a], key[b]); key[a] = lo_; key[b] = hi_; }
+    PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
+#undef PT_CSWAP
+    auto child_of = [&](uint32_t k) { const uint32_t s_ = k & 3u; return s_ == 0 ? c[0] : (s_ == 1 ? c[1] : (s_ == 2 ? c[2] : c[3])); };
+    if (key[0] == 0xFFFFFFFFu) return wide_pop<STRIDE>(st, sp);
+    // the other hits (a prefix of key[1..3]) go on the stack, farthest first
+    const int n = (key[1] != 0xFFFFFFFFu) + (key[2] != 0xFFFFFFFFu) + (key[3] != 0xFFFFFFFFu);
+    const int c1 = child_of(key[1]), c2 = child_of(key[2]), c3 = child_of(key[3]);
+    if (__builtin_expect(sp + n <= kWideLds, 1)) {  // all within the LDS part
+        PT_STACK_CHECK(sp + n - 1, kWideStack);
+        int* top = st.lds + (sp + n) * STRIDE;
+        if (n >= 1) top[-1 * STRIDE] = c1;
+        if (n >= 2) top[-2 * STRIDE] = c2;
+        if (n >= 3) top[-3 * STRIDE] = c3;
+        sp += n;
+    } else {
+        if (n >= 3) wide_push<STRIDE>(st, sp, c3);
+        if (n >= 2) wide_push<STRIDE>(st, sp, c2);
+        if (n >= 1) wide_push<STRIDE>(st, sp, c1);
+    }
+    return child_of(key[0]);
+}
+
 // BVH traversal of the rays [begin, end) by one wave, stack in LDS laid out [entry][lane]
 // (bank = lane: conflict-free).  ANY = stop at the first accepted triangle (shadow rays).
 //
@@ -259,6 +343,9 @@ struct RangePool {
 template <int DEPTH, bool ANY, bool STATS, class Fetch, class Done>
 __device__ __forceinline__ void trace_range_vote(const Scene& sc, uint32_t begin, uint32_t end, RangePool pool, int* stk,
                                                  Fetch fetch, Done done, uint32_t& n_nodes, uint32_t& n_tris) {
+    constexpr bool WIDE = DEPTH > 8;  // deep trees are walked through their four-wide nodes
+    int spill[WIDE ? kWideSpill : 1];
+    const WideStack wst{stk, spill};
     uint32_t cursor = begin;  // wave-uniform: first unclaimed ray
     bool more = pool.cursors != nullptr;  // wave-uniform: the pool may hold further ranges
     bool busy = false;
@@ -279,10 +366,13 @@ __device__ __forceinline__ void trace_range_vote(const Scene& sc, uint32_t begin
         const int n_node = __popcll(__ballot(is_node)), n_tri = __popcll(__ballot(is_tri)), n_ret = __popcll(m_ret);
         if (n_node >= n_tri && n_node >= n_ret) {
             if (n_node == 0) break;  // nothing left in the range
-            if (is_node) cur = node_step<DEPTH, STATS>(sc, cur, rf, t_min32, t_max32, stk, sp, n_nodes);
+            if (is_node) {
+                if (WIDE) cur = node4_step<STATS, kTravBlock>(sc, cur, rf, t_min32, t_max32, wst, sp, n_nodes);
+                else cur = node_step<DEPTH, STATS>(sc, cur, rf, t_min32, t_max32, stk, sp, n_nodes);
+            }
         } else if (n_tri >= n_ret) {
             if (is_tri) {
-                uint32_t code = (uint32_t)~cur, first = code >> 3, cnt = (code & 7u) + 1u;
+                const uint32_t code = (uint32_t)~cur, first = code >> 3, cnt = (code & 7u) + 1u;
                 bool stop = false;
                 for (uint32_t k = 0; k < cnt; ++k) {
                     const float4* tp = sc.tris + (size_t)(first + k) * 3;
@@ -299,7 +389,9 @@ __device__ __forceinline__ void trace_range_vote(const Scene& sc, uint32_t begin
                     t_max32 = f32_up(t);
                     if (ANY) { stop = true; break; }
                 }
-                if (stop || sp == 0) cur = kDone;
+                if (stop) cur = kDone;
+                else if (WIDE) cur = wide_pop<kTravBlock>(wst, sp);
+                else if (sp == 0) cur = kDone;
                 else { --sp; cur = stk[sp * kTravBlock]; }
             }
         } else {
@@ -344,13 +436,19 @@ __device__ __forceinline__ uint32_t traverse(const Scene& sc, D3 o, D3 d, double
         if (ANY && best != PT_MISS) return best;
     }
     if (sc.n_nodes == 0) return best;
+    constexpr bool WIDE = DEPTH > 8;
+    int spill[WIDE ? kWideSpill : 1];
+    const WideStack wst{stk, spill};
     const RayF rf = make_rayf(o, d);
     const float t_min32 = f32_down(t_min);
     float t_max32 = f32_up(t_max);
     int sp = 0;
     int cur = 0;
     while (cur != kDone) {
-        while (cur >= 0) cur = node_step<DEPTH, STATS, STRIDE>(sc, cur, rf, t_min32, t_max32, stk, sp, n_nodes);
+        while (cur >= 0) {
+            if (WIDE) cur = node4_step<STATS, STRIDE>(sc, cur, rf, t_min32, t_max32, wst, sp, n_nodes);
+            else cur = node_step<DEPTH, STATS, STRIDE>(sc, cur, rf, t_min32, t_max32, stk, sp, n_nodes);
+        }
         if (cur == kDone) break;
         int code = ~cur;
         uint32_t first = (uint32_t)code >> 3, cnt = ((uint32_t)code & 7u) + 1u;
@@ -369,6 +467,7 @@ __device__ __forceinline__ uint32_t traverse(const Scene& sc, D3 o, D3 d, double
             t_max32 = f32_up(t);
             if (ANY) return best;
         }
+        if (WIDE) { cur = wide_pop<STRIDE>(wst, sp); continue; }
         if (sp == 0) break;
         --sp;
         cur = stk[sp * STRIDE];
@@ -524,8 +623,13 @@ __host__ __device__ __forceinline__ uint32_t trav_blocks(uint32_t n, uint32_t wa
 // PRIMARY: the generate stage (main.rs:412-427 + scene.rs:37-45) runs in the fetch — ray i is path
 // slot i of the batch and its camera ray is built in registers; nothing is read from the queue.
 // One wave per workgroup; workgroup b owns the wave_rays queue entries [b, b+1) * wave_rays.
+// Five waves per SIMD for the traversal kernels (at most 96 VGPRs; they would take 100-104 and run four):
+// measured on the 10 M-triangle scene 4 / 5 / 6 waves -> 8.86 / 9.17 / 7.32 Gsamples/s (six spills).
+#ifndef PT_TRAV_WAVES
+#define PT_TRAV_WAVES 5
+#endif
 template <int DEPTH, bool STATS, bool PRIMARY, bool VOTE>
-__global__ __launch_bounds__(kTravBlock) void k_extend(Scene sc, Frame fr, Queue q, const double* __restrict__ tmin,
+__global__ __launch_bounds__(kTravBlock, PT_TRAV_WAVES) void k_extend(Scene sc, Frame fr, Queue q, const double* __restrict__ tmin,
                                                    const double* __restrict__ tmax, Live live, uint32_t wave_rays,
                                                    Hits hits, Counters* ctr) {
     __shared__ int stack[DEPTH * kTravBlock];
@@ -622,7 +726,7 @@ __device__ __forceinline__ void radiance_add(const Sample3& ls, uint32_t slot, D
 }
 
 template <int DEPTH, bool VOTE>
-__global__ __launch_bounds__(kTravBlock) void k_shadow(Scene sc, ShadowQueue sq, Live live, uint32_t wave_rays, Sample3 ls,
+__global__ __launch_bounds__(kTravBlock, PT_TRAV_WAVES) void k_shadow(Scene sc, ShadowQueue sq, Live live, uint32_t wave_rays, Sample3 ls,
                                                    Counters* ctr) {
     __shared__ int stack[DEPTH * kTravBlock];
     if (ctr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->shadow_rays, live_total(live));
