@@ -132,8 +132,9 @@ struct Ray {
 struct Surface {
     V3 position{0, 0, 0}, normal{0, 1, 0};
     V2 uv{0, 0};
-    V3 dpdu{0, 0, 0}, dpdv{0, 0, 0}, dpdx{0, 0, 0}, dpdy{0, 0, 0};
+    V3 dpdu{0, 0, 0}, dpdv{0, 0, 0}, dndu{0, 0, 0}, dndv{0, 0, 0}, dpdx{0, 0, 0}, dpdy{0, 0, 0};
     double dudx = 0, dvdx = 0, dudy = 0, dvdy = 0;
+    bool curved = false;  // dndu / dndv were set (Sphere::intersect); every other surface leaves them zero
 };
 
 // surface.rs:112-123
@@ -810,11 +811,41 @@ inline double sphere_light_pdf_dir(const Scene& sc, V3 normal_at_hit, V3 dir, do
     if (cos_l <= 0.) return 0.;
     return dist * dist / (sc.light_cdf.back() * cos_l);
 }
-// the hit point of an analytic primitive: Surface::new(position, normal) (mod.rs:46,71-72)
-inline Surface prim_surface(const Prim& pr, const Ray& ray, double t) {
+// The hit point of an analytic primitive.  A plane is Surface::new(position, normal) (mod.rs:45): no uv,
+// no derivatives.  A sphere (mod.rs:73-146) carries the derivatives of its (phi, theta) parametrisation and
+// of its normal (Weingarten equations), then the ray's differentials; its uv stays (0, 0).  At the poles
+// zRadius is 0 and the reference's own 0 * inf gives NaN derivatives; that is kept.
+inline Surface prim_surface(const Prim& pr, const Ray& ray, double t, bool use_diffs) {
     Surface s;
     s.position = ray.origin + ray.direction * t;
-    s.normal = pr.kind == PT_PRIM_PLANE ? pr.n : normalize(s.position - pr.p);
+    if (pr.kind == PT_PRIM_PLANE) {
+        s.normal = pr.n;
+        return s;
+    }
+    s.normal = normalize(s.position - pr.p);
+    V3 hit_local = s.position - pr.p;
+    double inner = hit_local.z / pr.radius;
+    if (inner < -1. || inner >= 1.) inner = 1.;
+    double theta = std::acos(inner);
+    double z_radius = std::sqrt(hit_local.x * hit_local.x + hit_local.y * hit_local.y);
+    double inv_z_radius = 1. / z_radius;
+    double cos_phi = hit_local.x * inv_z_radius;
+    double sin_phi = hit_local.y * inv_z_radius;
+    V3 dpdu = v3(-2. * PI * hit_local.y, 2. * PI * hit_local.x, 0.);
+    V3 dpdv = v3(hit_local.z * cos_phi, hit_local.z * sin_phi, -pr.radius * std::sin(theta)) * -PI;
+    V3 d2Pduu = -2. * PI * 2. * PI * v3(hit_local.x, hit_local.y, 0.);
+    V3 d2Pduv = (-PI) * hit_local.z * 2. * PI * v3(-sin_phi, cos_phi, 0.);
+    V3 d2Pdvv = -(-PI) * (-PI) * v3(hit_local.x, hit_local.y, hit_local.z);
+    double E = dot(dpdu, dpdu), F = dot(dpdu, dpdv), G = dot(dpdv, dpdv);
+    V3 N = normalize(cross(dpdu, dpdv));
+    double e = dot(N, d2Pduu), f = dot(N, d2Pduv), g = dot(N, d2Pdvv);
+    double invEGF2 = 1. / (E * G - F * F);
+    s.dpdu = dpdu;
+    s.dpdv = dpdv;
+    s.dndu = (f * F - e * G) * invEGF2 * dpdu + (e * F - f * E) * invEGF2 * dpdv;
+    s.dndv = (g * F - f * G) * invEGF2 * dpdu + (f * F - g * E) * invEGF2 * dpdv;
+    s.curved = true;
+    calculate_differentials(s, ray, use_diffs);
     return s;
 }
 
@@ -828,7 +859,8 @@ inline void create_tangent_vectors(V3 s, V3& v2, V3& v3_) {
 // reflect_diff for Lambertian / Glossy / Mirror and the reflected branch of Transparent,
 // refract_diff for the refracted branch.  surface.dndu = surface.dndv = 0 on every surface the
 // reference's triangles and Surface::new build (surface.rs:40-41; triangle_mesh.rs never sets
-// them), so dndx = dndy = 0 and the terms they multiply (which add only signed zeros) are dropped.
+// them), so there dndx = dndy = 0 and the terms they multiply (which add only signed zeros) are
+// dropped; a sphere sets them (mod.rs:131-132) and takes the full expressions.
 inline Ray spawn_with_diffs(const Surface& s, const Ray& inc, const Material& m, const BrdfSample& bs,
                             const pt_render_params& P) {
     Ray nr(s.position, bs.wi);
@@ -849,6 +881,24 @@ inline Ray spawn_with_diffs(const Surface& s, const Ray& inc, const Material& m,
     V3 normal = cos_theta < 0. ? -s.normal : s.normal;
     V3 dwodx = -inc.rx_direction - wo;
     V3 dwody = -inc.ry_direction - wo;
+    if (s.curved) {  // main.rs:210-221, 268-275 in full
+        V3 dndx = s.dndu * s.dudx + s.dndv * s.dvdx;
+        V3 dndy = s.dndu * s.dudy + s.dndv * s.dvdy;
+        double dDNdx = dot(dwodx, normal) + dot(wo, dndx);
+        double dDNdy = dot(dwody, normal) + dot(wo, dndy);
+        if (bs.lobe == 1) {
+            nr.rx_direction = wi - dwodx + 2. * (dot(wo, normal) * dndx + dDNdx * normal);
+            nr.ry_direction = wi - dwody + 2. * (dot(wo, normal) * dndy + dDNdy * normal);
+        } else {
+            double eta = cos_theta < 0. ? m.ior / 1. : 1. / m.ior;
+            double mu = eta * dot(-wo, normal) - dot(wi, normal);
+            double dmudx = (eta - (eta * eta * dot(-wo, normal)) / dot(wi, normal)) * dDNdx;
+            double dmudy = (eta - (eta * eta * dot(-wo, normal)) / dot(wi, normal)) * dDNdy;
+            nr.rx_direction = wi + eta * dwodx - (mu * dndx + dmudx * normal);
+            nr.ry_direction = wi + eta * dwody - (mu * dndy + dmudy * normal);
+        }
+        return nr;
+    }
     double dDNdx = dot(dwodx, normal);
     double dDNdy = dot(dwody, normal);
     if (bs.lobe == 1) {  // main.rs:258-276
@@ -889,7 +939,7 @@ inline V3 render(const Scene& sc, double x, double y, double pdx, double pdy, ui
         const Material& m = sc.mats[on_prim ? sc.prims[h.tri - PT_PRIM_BASE].mat : tr.mat];
         Ray hit_ray = trace_ray;
         hit_ray.t_max = h.t;
-        Surface surface = on_prim ? prim_surface(sc.prims[h.tri - PT_PRIM_BASE], hit_ray, h.t)
+        Surface surface = on_prim ? prim_surface(sc.prims[h.tri - PT_PRIM_BASE], hit_ray, h.t, use_diffs)
                                   : tri_surface(tr, hit_ray, h.t, h.v, h.w, use_diffs);
 
         V3 le = emission_of(m);
@@ -1161,7 +1211,7 @@ int orc_sample_brdf(const orc_scene* s, const pt_ray* rays, const uint32_t* tri_
         double tt, v, w;
         if (on_prim || !tri_test(tr, r.origin, r.direction, -INFINITY, INFINITY, tt, v, w)) { v = 0; w = 0; }
         r.t_max = t[i];
-        Surface surf = on_prim ? prim_surface(sc.prims[tri_id[i] - PT_PRIM_BASE], r, t[i]) : tri_surface(tr, r, t[i], v, w, use_diffs);
+        Surface surf = on_prim ? prim_surface(sc.prims[tri_id[i] - PT_PRIM_BASE], r, t[i], use_diffs) : tri_surface(tr, r, t[i], v, w, use_diffs);
         const Material& m = sc.mats[on_prim ? sc.prims[tri_id[i] - PT_PRIM_BASE].mat : tr.mat];
         double xi[2];
         uniform2(seed, pixel[i], sample, bounce, STREAM_BRDF, xi);
@@ -1271,6 +1321,22 @@ void orc_spawn_diffs(const double* in21, const double wi[3], int kind, int lobe,
     Ray r = spawn_with_diffs(s, inc, m, bs, P);
     const V3 o[4] = {r.rx_origin, r.ry_origin, r.rx_direction, r.ry_direction};
     for (int k = 0; k < 4; ++k) { out12[3 * k] = o[k].x; out12[3 * k + 1] = o[k].y; out12[3 * k + 2] = o[k].z; }
+}
+// Sphere::intersect's surface (geometry/mod.rs:73-146) for a ray known to hit at distance t, with the
+// ray's differentials in ray21 = (o, d, rx_origin, ry_origin, rx_direction, ry_direction, unused):
+// out22 = position, normal, dpdu, dpdv, dndu, dndv (18), then dudx, dvdx, dudy, dvdy.
+void orc_sphere_surface(const double centre[3], double radius, const double* ray18, double t, double* out22) {
+    auto at = [&](int k) { return v3(ray18[3 * k], ray18[3 * k + 1], ray18[3 * k + 2]); };
+    Prim pr{};
+    pr.kind = PT_PRIM_SPHERE;
+    pr.p = v3(centre[0], centre[1], centre[2]);
+    pr.radius = radius;
+    Ray r(at(0), at(1));
+    r.rx_origin = at(2); r.ry_origin = at(3); r.rx_direction = at(4); r.ry_direction = at(5);
+    Surface s = prim_surface(pr, r, t, true);
+    const V3 o[6] = {s.position, s.normal, s.dpdu, s.dpdv, s.dndu, s.dndv};
+    for (int k = 0; k < 6; ++k) { out22[3 * k] = o[k].x; out22[3 * k + 1] = o[k].y; out22[3 * k + 2] = o[k].z; }
+    out22[18] = s.dudx; out22[19] = s.dvdx; out22[20] = s.dudy; out22[21] = s.dvdy;
 }
 // lights.rs:7-15 sample_sphere (dormant AreaLight path, kept for its known answer: |p| = 1)
 void orc_sample_sphere(double rnd, double rnd2, double* out3) {

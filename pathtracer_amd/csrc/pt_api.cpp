@@ -416,7 +416,6 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
         if (q.kind != PT_PRIM_SPHERE && q.kind != PT_PRIM_PLANE) { set_error("primitive %u: bad kind", k); return PT_ERR_INVALID; }
         if (q.material >= d->n_mats) { set_error("primitive %u: material out of range", k); return PT_ERR_INVALID; }
         const pt_material& m = d->mats[q.material];
-        if (m.tex >= 0) { set_error("primitive %u: textured materials need triangle uvs", k); return PT_ERR_UNSUPPORTED; }
         bool emissive = m.kind == PT_MAT_LAMBERT && (m.emission[0] != 0.f || m.emission[1] != 0.f || m.emission[2] != 0.f);
         if (emissive && q.kind == PT_PRIM_PLANE) { set_error("primitive %u: an emissive plane has infinite area", k); return PT_ERR_UNSUPPORTED; }
         if (q.kind == PT_PRIM_SPHERE && !(q.radius > 0.)) { set_error("primitive %u: sphere radius must be positive", k); return PT_ERR_INVALID; }

@@ -100,6 +100,45 @@ __device__ __forceinline__ bool surface_dp(D3 normal, D3 position, const RayDiff
     dpdy = py - position;
     return true;
 }
+// surface.rs:86-108: the texture-space derivatives from dpdu / dpdv and the screen-space dpdx / dpdy
+__device__ __forceinline__ void uv_derivs(D3 normal, D3 dpdu, D3 dpdv, D3 dpdx, D3 dpdy, double& dudx, double& dvdx,
+                                          double& dudy, double& dvdy) {
+    int d0, d1;
+    if (fabs(normal.x) > fabs(normal.y) && fabs(normal.x) > fabs(normal.z)) { d0 = 1; d1 = 2; }
+    else if (fabs(normal.y) > fabs(normal.z)) { d0 = 0; d1 = 2; }
+    else { d0 = 0; d1 = 1; }
+    double a00 = comp(dpdu, d0), a01 = comp(dpdv, d0), a10 = comp(dpdu, d1), a11 = comp(dpdv, d1);
+    solve2x2(a00, a01, a10, a11, comp(dpdx, d0), comp(dpdx, d1), dudx, dvdx);
+    solve2x2(a00, a01, a10, a11, comp(dpdy, d0), comp(dpdy, d1), dudy, dvdy);
+}
+// geometry/mod.rs:76-132: the derivatives of a sphere's (phi, theta) parametrisation at a hit and, from the
+// fundamental forms, of its normal.  `hit_local` = position - centre.  At the poles the reference's own
+// 0 * inf gives NaN; kept.
+struct SphereDerivs {
+    D3 dpdu, dpdv, dndu, dndv;
+};
+__device__ SphereDerivs sphere_derivs(D3 hit_local, double radius) {
+    double inner = hit_local.z / radius;
+    if (inner < -1. || inner >= 1.) inner = 1.;
+    double theta = acos(inner);
+    double z_radius = sqrt(hit_local.x * hit_local.x + hit_local.y * hit_local.y);
+    double inv_z_radius = 1. / z_radius;
+    double cos_phi = hit_local.x * inv_z_radius;
+    double sin_phi = hit_local.y * inv_z_radius;
+    SphereDerivs r;
+    r.dpdu = mk(-2. * PT_PI * hit_local.y, 2. * PT_PI * hit_local.x, 0.);
+    r.dpdv = mk(hit_local.z * cos_phi, hit_local.z * sin_phi, -radius * sin(theta)) * -PT_PI;
+    D3 d2Pduu = (-2. * PT_PI * 2. * PT_PI) * mk(hit_local.x, hit_local.y, 0.);
+    D3 d2Pduv = ((-PT_PI) * hit_local.z * 2. * PT_PI) * mk(-sin_phi, cos_phi, 0.);
+    D3 d2Pdvv = (-(-PT_PI) * (-PT_PI)) * mk(hit_local.x, hit_local.y, hit_local.z);
+    double E = dot(r.dpdu, r.dpdu), F = dot(r.dpdu, r.dpdv), G = dot(r.dpdv, r.dpdv);
+    D3 N = normalize(cross(r.dpdu, r.dpdv));
+    double e = dot(N, d2Pduu), f = dot(N, d2Pduv), g = dot(N, d2Pdvv);
+    double invEGF2 = 1. / (E * G - F * F);
+    r.dndu = ((f * F - e * G) * invEGF2) * r.dpdu + ((e * F - f * E) * invEGF2) * r.dpdv;
+    r.dndv = ((g * F - f * G) * invEGF2) * r.dpdu + ((f * F - g * E) * invEGF2) * r.dpdv;
+    return r;
+}
 // Diffuse colour of a textured Lambertian at a hit: uv interpolation + dpdu/dpdv
 // (triangle_mesh.rs:128-138), ray differentials (surface.rs:86-109), material.rs:100-111.
 // `has_dp`: dpdx / dpdy hold surface_dp's result for a ray that carries differentials (a primary
@@ -134,15 +173,21 @@ __device__ D3 textured_color(const Scene& sc, const Material& m, const TriV& tr,
         double inverse_det = 1. / determinant;
         D3 dpdu = (duv12y * dp02 - duv02y * dp12) * inverse_det;
         D3 dpdv = (-duv12x * dp02 + duv02x * dp12) * inverse_det;
-        int d0, d1;
-        if (fabs(normal.x) > fabs(normal.y) && fabs(normal.x) > fabs(normal.z)) { d0 = 1; d1 = 2; }
-        else if (fabs(normal.y) > fabs(normal.z)) { d0 = 0; d1 = 2; }
-        else { d0 = 0; d1 = 1; }
-        double a00 = comp(dpdu, d0), a01 = comp(dpdv, d0), a10 = comp(dpdu, d1), a11 = comp(dpdv, d1);
-        solve2x2(a00, a01, a10, a11, comp(dpdx, d0), comp(dpdx, d1), dudx, dvdx);
-        solve2x2(a00, a01, a10, a11, comp(dpdy, d0), comp(dpdy, d1), dudy, dvdy);
+        uv_derivs(normal, dpdu, dpdv, dpdx, dpdy, dudx, dvdx, dudy, dvdy);
     }
     return sample_mipmap(sc.texs[m.tex], tu, tv, dudx, dvdx, dudy, dvdy);
+}
+
+// The same for an analytic primitive: its uv stays (0, 0) (Surface::default, surface.rs:35); a plane has no
+// derivatives (Surface::new, geometry/mod.rs:45), a sphere those of sphere_derivs (mod.rs:136-145).
+__device__ D3 prim_textured_color(const Scene& sc, const Material& m, const Prim& pr, D3 position, D3 normal,
+                                  bool has_dp, D3 dpdx, D3 dpdy) {
+    double dudx = 0., dvdx = 0., dudy = 0., dvdy = 0.;
+    if (has_dp && pr.kind == PT_PRIM_SPHERE) {
+        const SphereDerivs sd = sphere_derivs(position - ld3(pr.p), pr.radius);
+        uv_derivs(normal, sd.dpdu, sd.dpdv, dpdx, dpdy, dudx, dvdx, dudy, dvdy);
+    }
+    return sample_mipmap(sc.texs[m.tex], 0., 0., dudx, dvdx, dudy, dvdy);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -269,10 +314,12 @@ __device__ __forceinline__ D3 specular_sample(const Material& m, D3 ray_dir, D3 
 // The differential rays of the ray the legacy integrator spawns at a vertex (main.rs:192-281,
 // commented out in the reference): reflect_diff for a Lambertian / Glossy sample (lobe 0) and a
 // specular reflection (lobe 1), refract_diff for a refraction (lobe 2).  dndu = dndv = 0 on every
-// surface the reference builds for a triangle or with Surface::new (surface.rs:40-41), so the
-// dndx / dndy terms, which add only signed zeros, are dropped.
+// surface the reference builds for a triangle or with Surface::new (surface.rs:40-41), so there the
+// dndx / dndy terms, which add only signed zeros, are dropped; a sphere sets them (geometry/mod.rs:131-132):
+// `curved` with dndx = dndu dudx + dndv dvdx, dndy likewise (main.rs:210-211, 268-269).
 __device__ RayDiffs spawn_diffs(const Material& m, int lobe, D3 position, D3 surf_normal, D3 dpdx, D3 dpdy, D3 inc_dir,
-                                const RayDiffs& inc, D3 wi, double diff_size, bool roughdiff) {
+                                const RayDiffs& inc, D3 wi, double diff_size, bool roughdiff, bool curved = false,
+                                D3 dndx = D3{0., 0., 0.}, D3 dndy = D3{0., 0., 0.}) {
     RayDiffs nr;
     D3 wo = -inc_dir;
     nr.rxo = position + dpdx;
@@ -291,6 +338,22 @@ __device__ RayDiffs spawn_diffs(const Material& m, int lobe, D3 position, D3 sur
     D3 normal = cos_theta < 0. ? -surf_normal : surf_normal;
     D3 dwodx = -inc.rxd - wo;
     D3 dwody = -inc.ryd - wo;
+    if (curved) {  // main.rs:210-221, 268-275 in full
+        double dDNdx = dot(dwodx, normal) + dot(wo, dndx);
+        double dDNdy = dot(dwody, normal) + dot(wo, dndy);
+        if (lobe == 1) {
+            nr.rxd = wi - dwodx + 2. * (dot(wo, normal) * dndx + dDNdx * normal);
+            nr.ryd = wi - dwody + 2. * (dot(wo, normal) * dndy + dDNdy * normal);
+        } else {
+            double eta = cos_theta < 0. ? m.ior / 1. : 1. / m.ior;
+            double mu = eta * dot(-wo, normal) - dot(wi, normal);
+            double dmudx = (eta - (eta * eta * dot(-wo, normal)) / dot(wi, normal)) * dDNdx;
+            double dmudy = (eta - (eta * eta * dot(-wo, normal)) / dot(wi, normal)) * dDNdy;
+            nr.rxd = wi + eta * dwodx - (mu * dndx + dmudx * normal);
+            nr.ryd = wi + eta * dwody - (mu * dndy + dmudy * normal);
+        }
+        return nr;
+    }
     double dDNdx = dot(dwodx, normal);
     double dDNdy = dot(dwody, normal);
     if (lobe == 1) {  // main.rs:258-276
@@ -399,9 +462,15 @@ __device__ __forceinline__ D3 diffuse_of(const Scene& sc, const Material& m, uin
                                          D3 d, D3 position, D3 normal, const Frame& fr, bool primary,
                                          uint32_t pixel, uint32_t s) {
     if (m.tex < 0) return ld3(m.color);
-    const TriV tr = load_tri(sc, leaf);  // only a textured hit needs the vertices again (uv, dpdu, dpdv)
     bool has_dp = false;
     D3 dpdx = mk(0., 0., 0.), dpdy = dpdx;
+    if (leaf >= PT_PRIM_BASE) {
+        const Prim& pr = sc.prims[leaf - PT_PRIM_BASE];
+        if (pr.kind == PT_PRIM_SPHERE && primary && (fr.flags & PT_FLAG_USE_DIFFS))
+            has_dp = surface_dp(normal, position, camera_diffs(sc, fr, o, pixel, s), dpdx, dpdy);
+        return prim_textured_color(sc, m, pr, position, normal, has_dp, dpdx, dpdy);
+    }
+    const TriV tr = load_tri(sc, leaf);  // only a textured hit needs the vertices again (uv, dpdu, dpdv)
     if (primary && (fr.flags & PT_FLAG_USE_DIFFS))
         has_dp = surface_dp(normal, position, camera_diffs(sc, fr, o, pixel, s), dpdx, dpdy);
     return textured_color(sc, m, tr, leaf, o, d, normal, has_dp, dpdx, dpdy);
@@ -564,7 +633,8 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
         if (!LAST) {
             D3 diffuse = mk(0., 0., 0.);
             RayDiffs inc_diff;
-            D3 dpdx = mk(0., 0., 0.), dpdy = dpdx;
+            D3 dpdx = mk(0., 0., 0.), dpdy = dpdx, dndx = dpdx, dndy = dpdx;
+            bool curved = false;
             if (DIFFS) {  // surface.rs:59-84 for the ray's own differentials, at every vertex
                 if (FIRST) {
                     inc_diff = camera_diffs(sc, fr, o, pixel, s);
@@ -576,11 +646,23 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
                     inc_diff.rxd = mk(q[6 * st], q[7 * st], q[8 * st]);
                     inc_diff.ryd = mk(q[9 * st], q[10 * st], q[11 * st]);
                 }
-                // an analytic primitive's surface is Surface::new (geometry/mod.rs:46,71): no differentials
-                bool has_dp = leaf < PT_PRIM_BASE && surface_dp(normal, position, inc_diff, dpdx, dpdy);
-                if (m.kind == PT_MAT_LAMBERT)
-                    diffuse = m.tex < 0 ? ld3(m.color)
-                                        : textured_color(sc, m, load_tri(sc, leaf), leaf, o, d, normal, has_dp, dpdx, dpdy);
+                // a plane's surface is Surface::new (geometry/mod.rs:45): no differentials; a sphere's has them
+                // and the derivatives of its normal (mod.rs:136-145)
+                const Prim* pr = leaf >= PT_PRIM_BASE ? sc.prims + (leaf - PT_PRIM_BASE) : nullptr;
+                curved = pr && pr->kind == PT_PRIM_SPHERE;
+                bool has_dp = (!pr || curved) && surface_dp(normal, position, inc_diff, dpdx, dpdy);
+                if (curved) {
+                    const SphereDerivs sd = sphere_derivs(position - ld3(pr->p), pr->radius);
+                    double dudx = 0., dvdx = 0., dudy = 0., dvdy = 0.;
+                    if (has_dp) uv_derivs(normal, sd.dpdu, sd.dpdv, dpdx, dpdy, dudx, dvdx, dudy, dvdy);
+                    dndx = sd.dndu * dudx + sd.dndv * dvdx;
+                    dndy = sd.dndu * dudy + sd.dndv * dvdy;
+                }
+                if (m.kind == PT_MAT_LAMBERT) {
+                    if (m.tex < 0) diffuse = ld3(m.color);
+                    else if (pr) diffuse = prim_textured_color(sc, m, *pr, position, normal, has_dp, dpdx, dpdy);
+                    else diffuse = textured_color(sc, m, load_tri(sc, leaf), leaf, o, d, normal, has_dp, dpdx, dpdy);
+                }
             } else if (!SPEC || m.kind == PT_MAT_LAMBERT) {
                 diffuse = TEX ? diffuse_of(sc, m, leaf, o, d, position, normal, fr, FIRST, pixel, s) : ld3(m.color);
             }
@@ -678,7 +760,7 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
                 r.n_o = position;  // main.rs:314
                 if (DIFFS)
                     r.n_diff = spawn_diffs(m, lobe, position, normal, dpdx, dpdy, d, inc_diff, r.n_d, fr.diff_size,
-                                           (fr.flags & PT_FLAG_ROUGHDIFF) != 0);
+                                           (fr.flags & PT_FLAG_ROUGHDIFF) != 0, curved, dndx, dndy);
                 r.alive = true;
                 if (sc.cull_last && bounce + 1 == fr.max_bounces) r.alive = may_reach_emitter(sc, r.n_o, r.n_d, r.n_T);
             }

@@ -25,3 +25,22 @@ def gpu():
     if not _gpu_available():
         pytest.skip("no GPU")
     return 0
+
+
+def record_parity(name, values):
+    """Achieved parity numbers of a GPU test, merged into a JSON file (copied to profiles/<round>/parity.json
+    after the run): PT_PARITY_JSON, else gpurun_out/parity.json under the repository."""
+    import json
+    path = os.environ.get("PT_PARITY_JSON") or os.path.join(ROOT, "gpurun_out", "parity.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        try:
+            with open(path) as f:
+                allv = json.load(f)
+        except (OSError, ValueError):
+            allv = {}
+        allv[name] = values
+        with open(path, "w") as f:
+            json.dump(allv, f, indent=1, sort_keys=True)
+    except OSError:
+        pass

@@ -60,6 +60,8 @@ lib.orc_fresnel_dielectric.argtypes = [C.c_double, C.c_double]
 lib.orc_fresnel_dielectric.restype = C.c_double
 lib.orc_spawn_diffs.argtypes = [_dp, _dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_uint32, _dp]
 lib.orc_spawn_diffs.restype = None
+lib.orc_sphere_surface.argtypes = [_dp, C.c_double, _dp, C.c_double, _dp]
+lib.orc_sphere_surface.restype = None
 lib.orc_refract.argtypes = [_dp, _dp, C.c_double, _dp]
 lib.orc_refract.restype = None
 lib.orc_normalize.argtypes = [_dp, _dp]
@@ -230,6 +232,21 @@ def spawn_diffs(position, normal, dpdx, dpdy, inc_dir, inc_rx_dir, inc_ry_dir, w
     out = (C.c_double * 12)()
     lib.orc_spawn_diffs(vin.ctypes.data_as(_dp), _d3(wi), kind, lobe, roughness, ior, diff_size, flags, out)
     return np.array(out[:]).reshape(4, 3)
+
+
+def sphere_surface(centre, radius, origin, direction, t, rx_origin=None, ry_origin=None, rx_direction=None,
+                   ry_direction=None):
+    """geometry/mod.rs:73-146: the Surface of a sphere hit, as a dict of its fields."""
+    z = np.zeros(3)
+    ray = np.ascontiguousarray(np.concatenate([np.asarray(v, np.float64) if v is not None else z for v in
+                                               (origin, direction, rx_origin, ry_origin, rx_direction, ry_direction)]))
+    out = (C.c_double * 22)()
+    lib.orc_sphere_surface(_d3(centre), float(radius), ray.ctypes.data_as(_dp), float(t), out)
+    a = np.array(out[:])
+    names = ("position", "normal", "dpdu", "dpdv", "dndu", "dndv")
+    r = {n: a[3 * i:3 * i + 3] for i, n in enumerate(names)}
+    r.update(dudx=a[18], dvdx=a[19], dudy=a[20], dvdy=a[21])
+    return r
 
 
 def ggx_D(roughness, m, n):

@@ -9,8 +9,29 @@ import pytest
 
 import pathtracer_amd as pt
 import oracle_lib as O
+from conftest import record_parity
 
 pytestmark = pytest.mark.gpu
+
+
+def parity_numbers(a, b, tol, spp):
+    """What a GPU-vs-oracle image comparison achieved (a, b: accumulated f64 sums of `spp` frames)."""
+    fin = np.isfinite(a) & np.isfinite(b)
+    rel = np.abs(a - b)[fin] / np.maximum(1.0, np.abs(b[fin]))
+    qa = pt.resolve_rgb8(np.nan_to_num(a), spp).astype(np.float64)
+    qb = pt.resolve_rgb8(np.nan_to_num(b), spp).astype(np.float64)
+    mse = ((qa - qb) ** 2).mean()
+    return {
+        "values": int(a.size), "spp": int(spp), "tolerance": tol,
+        "rel_rmse": float(np.sqrt(((a - b)[fin] ** 2).mean()) / max(np.sqrt((b[fin] ** 2).mean()), 1e-300)),
+        "max_rel_err": float(rel.max()) if rel.size else 0.0,
+        "fraction_over_tolerance": float((rel > tol).mean()) if rel.size else 0.0,
+        "psnr_8bit_db": None if mse == 0 else float(10 * np.log10(255.0 ** 2 / mse)),
+        "identical_8bit": bool(mse == 0),
+        "mean_rel_diff": float(abs(a[fin].mean() - b[fin].mean()) / max(abs(b[fin].mean()), 1e-300)),
+        "nonfinite_gpu": int((~np.isfinite(a)).sum()), "nonfinite_oracle": int((~np.isfinite(b)).sum()),
+        "nonfinite_mask_mismatch": int((np.isfinite(a) != np.isfinite(b)).sum()),
+    }
 
 SCENES = ["CornellBox", "Test", "glossy_planes", "cornell_box"]
 
@@ -461,6 +482,7 @@ def test_baseline_full_size_glossy_and_textured(gpu, name, kw, width, height, sp
     for y in rows:
         oracle.render(cfg, ref, tile=(0, y, width, y + 1), threads=16)
     sub, rsub = whole[list(rows)], ref[list(rows)]
+    record_parity(f"full_size_{name}_{width}x{height}_{spp}spp", parity_numbers(sub, rsub, tol, spp))
     assert (np.abs(sub - rsub) > tol * np.maximum(1.0, np.abs(rsub))).mean() < frac
     assert abs(sub.mean() - rsub.mean()) <= 1e-3 * rsub.mean()
     acc = scene.render(cfg, None, sample_begin=0, sample_count=1)
@@ -632,6 +654,7 @@ def test_config2_converged_image_psnr(scenes):
     for y in rows:
         oracle.render(cfg, ref, tile=(0, y, 1920, y + 1), threads=16)
     a, b = img[rows], ref[rows]
+    record_parity("config2_CornellBox_1920x1080_1024spp", parity_numbers(a, b, 1e-9, spp))
     assert b.mean() > 1.0                                   # sums of 1024 samples
     rel_rmse = np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean())
     assert rel_rmse <= 1e-9, rel_rmse
@@ -657,9 +680,39 @@ def test_config3_converged_glossy_psnr(gpu):
     for y in rows:
         oracle.render(cfg, ref, tile=(0, y, 1920, y + 1), threads=16)
     a, b = img[rows], ref[rows]
+    record_parity("config3_glossy_planes_1920x1080_256spp_drop_nonfinite", parity_numbers(a, b, 1e-6, spp))
     assert np.isfinite(a).all() and np.isfinite(b).all() and b.mean() > 1.0
     assert abs(a.mean() - b.mean()) <= 1e-4 * b.mean()
     qa, qb = pt.resolve_rgb8(a, spp).astype(np.float64), pt.resolve_rgb8(b, spp).astype(np.float64)
     mse = ((qa - qb) ** 2).mean()
     psnr = np.inf if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
     assert psnr >= 50.0, psnr
+
+
+def test_config3_glossy_full_size_nonfinite_samples_as_the_reference(gpu):
+    # BASELINE.json configs[2] at its full size in the reference's own mode: non-finite samples (a Beckmann
+    # strip of width 1e-5 takes acos of a dot product that rounds past 1) are ACCUMULATED, as main.rs:434-436
+    # does, not dropped.  A pixel is then NaN on both sides or on neither, except where that rounding falls
+    # differently in ocml and glibc: stated bound, at most 1 pixel value in 10 000 differs in finiteness; the
+    # pixels finite on both sides agree as in the drop_nonfinite comparison (99.5 % within 1e-6).
+    # (Measured, profiles/r02/parity.json: at this size, seed and depth the whole device image holds no
+    # non-finite value at all, so the two modes coincide here; the small-size NaN-mask test is test_gpu_shading's.)
+    data = pt.scene_data("glossy_planes", glossy=True)
+    scene, oracle = pt.Scene(data, gpu), O.OracleScene(data)
+    spp = 32
+    cfg = pt.Config(width=1920, height=1080, samples_pr_pixel=spp, bounces=2, seed=4)
+    img = scene.render(cfg)
+    # 24 rows at a fixed stride, plus up to 16 of the rows where the device image holds a non-finite pixel
+    # (they are rare at this size; where there are none the recorded count says so)
+    bad_rows = np.flatnonzero(~np.isfinite(img).all(axis=(1, 2)))
+    rows = sorted(set(range(5, 1080, 45)) | set(int(y) for y in bad_rows[:16]))
+    ref = np.zeros_like(img)
+    for y in rows:
+        oracle.render(cfg, ref, tile=(0, y, 1920, y + 1), threads=16)
+    a, b = img[rows], ref[rows]
+    nums = parity_numbers(a, b, 1e-6, spp)
+    nums["rows_compared"] = len(rows)
+    nums["nonfinite_values_in_whole_gpu_image"] = int((~np.isfinite(img)).sum())
+    record_parity("config3_glossy_planes_1920x1080_32spp_nonfinite_accumulated", nums)
+    assert nums["nonfinite_mask_mismatch"] <= 1e-4 * a.size, nums
+    assert nums["fraction_over_tolerance"] < 5e-3, nums
