@@ -116,6 +116,14 @@ typedef struct pt_primitive {
     double radius;     /* sphere */
 } pt_primitive;
 
+/* lights.rs:37-40 AreaLight { mesh: &Sphere, intensity }.  The sphere is the light's sampling domain only:
+ * as in the reference, where Scene.lights and the scene's geometry are separate, it is not hit by rays. */
+typedef struct pt_area_light {
+    double center[3];
+    double radius;
+    double intensity[3];
+} pt_area_light;
+
 typedef struct pt_scene_desc {
     const float* verts;           /* [n_verts][3] positions, f32 as tobj delivers them (obj.rs:22-27) */
     uint32_t n_verts;
@@ -137,6 +145,9 @@ typedef struct pt_scene_desc {
     const uint32_t* bvh_tri_order; /* [n_tris] triangle ids in leaf order */
     const pt_primitive* prims;     /* analytic primitives, tested against every ray (at most PT_MAX_PRIMS) */
     uint32_t n_prims;
+    const pt_area_light* area_lights; /* Scene.lights (scene.rs:15) as the reference types them; used by
+                                         PT_FLAG_REFERENCE_LIGHTS only.  At most one. */
+    uint32_t n_area_lights;
 } pt_scene_desc;
 #define PT_MAX_PRIMS 256u
 
@@ -161,8 +172,20 @@ enum {
                                         * secondary hits are filtered (the live render() resets them,
                                         * main.rs:314).  Needs PT_FLAG_USE_DIFFS; ignored by scenes
                                         * without textures, where nothing reads a differential */
-    PT_FLAG_ROUGHDIFF = 1u << 5 /* CONFIG.roughdiff (main.rs:351): a Glossy vertex spreads the
-                                 * differentials by diff_size * roughness / 0.8 (main.rs:249-253) */
+    PT_FLAG_ROUGHDIFF = 1u << 5, /* CONFIG.roughdiff (main.rs:351): a Glossy vertex spreads the
+                                  * differentials by diff_size * roughness / 0.8 (main.rs:249-253) */
+    PT_FLAG_REFERENCE_LIGHTS = 1u << 6 /* the reference's dormant direct-light path as written (lights.rs:42-62,
+                                        * 70-78, 110-137), against pt_scene_desc::area_lights: a point drawn
+                                        * uniformly on the light's sphere (sample_sphere), rejected when it faces
+                                        * away, shadow ray to t_max = |diff|, irradiance = intensity / |diff|^2,
+                                        * pdf the constant 1 / (4 pi) whatever the radius, Ld = brdf(0,0,0)
+                                        * |wi . n| irradiance / pdf, no MIS (emission on a hit stays unweighted).
+                                        * EstimateDirect has no caller in the reference; here it is evaluated at
+                                        * every Lambertian vertex that is not the path's last, and
+                                        * throughput * Ld is added to the sample (other materials: the
+                                        * reference's zero-vector BRDF call is defined for Lambertian only).  It is
+                                        * NOT an unbiased estimator of a sphere emitter (tests/test_lights.py
+                                        * states what it converges to).  Excludes PT_FLAG_NEE. */
 };
 
 /* CONFIG of main.rs:320-379 plus the partitioning knobs of SURVEY.md §8e. */

@@ -484,6 +484,7 @@ struct Prim {  // geometry/mod.rs:20-29
 struct Scene {
     std::vector<Tri> tris;
     std::vector<Prim> prims;
+    std::vector<pt_area_light> area_lights;  // Scene.lights, scene.rs:15 (PT_FLAG_REFERENCE_LIGHTS)
     std::vector<Material> mats;
     std::vector<MipMap> texs;
     pt_camera cam;
@@ -918,7 +919,8 @@ inline Ray spawn_with_diffs(const Surface& s, const Ray& inc, const Material& m,
 inline V3 render(const Scene& sc, double x, double y, double pdx, double pdy, uint32_t pixel, uint64_t sample,
                  const pt_render_params& P, bool bvh) {
     bool use_diffs = (P.flags & PT_FLAG_USE_DIFFS) != 0;
-    bool nee = (P.flags & PT_FLAG_NEE) != 0 && !sc.lights.empty();
+    bool ref_lights = (P.flags & PT_FLAG_REFERENCE_LIGHTS) != 0 && !sc.area_lights.empty();
+    bool nee = !ref_lights && (P.flags & PT_FLAG_NEE) != 0 && !sc.lights.empty();
     bool propagate = use_diffs && (P.flags & PT_FLAG_PROPAGATE_DIFFS) != 0 && !sc.texs.empty();
     Ray trace_ray = camera_ray(sc.cam, x, y, pdx, pdy, use_diffs);
     V3 color_result = v3(0, 0, 0);
@@ -1000,6 +1002,36 @@ inline V3 render(const Scene& sc, double x, double y, double pdx, double pdy, ui
                     V3 lle = emission_of(sc.mats[light_mat]);
                     double wgt = p_l / (p_l + p_b);
                     color_result = color_result + accumulated_pdf * f * lle * (cosn * wgt / p_l);
+                }
+            }
+        }
+
+        // The reference's own direct-light path, as written: EstimateDirect (lights.rs:110-137) over
+        // AreaLight::sample (lights.rs:42-62) and Sphere::sample_surface (lights.rs:70-78).  It has no caller
+        // in the reference; the build evaluates it at every Lambertian vertex but the path's last and adds
+        // throughput * Ld (pt.h, PT_FLAG_REFERENCE_LIGHTS).
+        if (ref_lights && bounce < P.max_bounces && m.kind == PT_MAT_LAMBERT) {
+            const pt_area_light& al = sc.area_lights[0];
+            double r[2];
+            uniform2(P.seed, pixel, sample, bounce, STREAM_LIGHT, r);
+            double z = 1. - 2. * r[0];                       // sample_sphere, lights.rs:7-15
+            double rr = std::sqrt(std::fmax(0., 1. - z * z));
+            double phi = 2. * PI * r[1];
+            V3 unit_sample = v3(rr * std::cos(phi), rr * std::sin(phi), z);
+            V3 light_pos = unit_sample * al.radius + v3(al.center[0], al.center[1], al.center[2]);
+            double light_pdf = 0.25 * FRAC_1_PI;             // lights.rs:76, whatever the radius
+            V3 diff = light_pos - surface.position;
+            V3 light_direction = normalize(diff);
+            if (!(dot(unit_sample, -light_direction) < 0.)) {  // lights.rs:48-50
+                Ray shadow(surface.position, light_direction);
+                shadow.t_max = length(diff);                 // lights.rs:52
+                if (trace(sc, shadow, bvh).tri == PT_MISS) { // trace_any = closest hit (scene.rs:66-68)
+                    V3 irradiance = v3(al.intensity[0], al.intensity[1], al.intensity[2]) / dot(diff, diff);
+                    if (!(light_pdf < 1e-10)) {              // lights.rs:124-126
+                        V3 f = get_diffuse(sc, m, surface) * FRAC_1_PI * std::fabs(dot(light_direction, surface.normal));
+                        V3 Ld = f * irradiance / light_pdf;  // lights.rs:132-135
+                        color_result = color_result + accumulated_pdf * Ld;
+                    }
                 }
             }
         }
@@ -1089,6 +1121,8 @@ int orc_scene_create(const pt_scene_desc* d, orc_scene** out) {
         t.mat = d->tri_material ? d->tri_material[i] : 0;
         if (t.mat >= sc.mats.size()) { delete s; return PT_ERR_INVALID; }
     }
+    if (d->n_area_lights > 1) { delete s; return PT_ERR_UNSUPPORTED; }
+    for (uint32_t k = 0; k < d->n_area_lights; ++k) sc.area_lights.push_back(d->area_lights[k]);
     if (d->n_prims > PT_MAX_PRIMS) { delete s; return PT_ERR_UNSUPPORTED; }
     for (uint32_t k = 0; k < d->n_prims; ++k) {
         const pt_primitive& q = d->prims[k];

@@ -19,7 +19,7 @@ PT_OK, PT_ERR_INVALID, PT_ERR_NOMEM, PT_ERR_DEVICE, PT_ERR_IO, PT_ERR_UNSUPPORTE
 PT_MAT_LAMBERT, PT_MAT_GLOSSY, PT_MAT_MIRROR, PT_MAT_TRANSPARENT, PT_MAT_GLOSSY_GGX = 0, 1, 2, 3, 4
 PT_BVH_EMPTY = 0x7FFFFFFF
 PT_FLAG_USE_DIFFS, PT_FLAG_NEE, PT_FLAG_DROP_NONFINITE, PT_FLAG_RUSSIAN_ROULETTE = 1, 2, 4, 8
-PT_FLAG_PROPAGATE_DIFFS, PT_FLAG_ROUGHDIFF = 16, 32
+PT_FLAG_PROPAGATE_DIFFS, PT_FLAG_ROUGHDIFF, PT_FLAG_REFERENCE_LIGHTS = 16, 32, 64
 PT_LOAD_GLOSSY, PT_LOAD_TEXTURES, PT_LOAD_SPECULAR, PT_LOAD_GGX = 1, 2, 4, 8
 PT_K_GENERATE, PT_K_EXTEND, PT_K_SHADE, PT_K_SHADOW, PT_K_ACCUMULATE, PT_K_PATH, PT_K_COUNT = 0, 1, 2, 3, 4, 5, 6
 KERNEL_NAMES = ("generate", "extend", "shade", "shadow", "accumulate", "path")
@@ -48,6 +48,10 @@ class pt_primitive(C.Structure):
                 ("radius", C.c_double)]
 
 
+class pt_area_light(C.Structure):
+    _fields_ = [("center", C.c_double * 3), ("radius", C.c_double), ("intensity", C.c_double * 3)]
+
+
 class pt_scene_desc(C.Structure):
     _fields_ = [("verts", C.POINTER(C.c_float)), ("n_verts", C.c_uint32),
                 ("tris", C.POINTER(C.c_uint32)), ("n_tris", C.c_uint32),
@@ -58,7 +62,8 @@ class pt_scene_desc(C.Structure):
                 ("camera", pt_camera), ("background", C.c_double * 3),
                 ("bvh_nodes", C.POINTER(pt_bvh_node)), ("n_bvh_nodes", C.c_uint32),
                 ("bvh_tri_order", C.POINTER(C.c_uint32)),
-                ("prims", C.POINTER(pt_primitive)), ("n_prims", C.c_uint32)]
+                ("prims", C.POINTER(pt_primitive)), ("n_prims", C.c_uint32),
+                ("area_lights", C.POINTER(pt_area_light)), ("n_area_lights", C.c_uint32)]
 
 
 class pt_ray(C.Structure):

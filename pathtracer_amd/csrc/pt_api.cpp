@@ -341,6 +341,10 @@ int check_params(const pt_render_params* p) {
         set_error("bad row partition: group %u, part %u of %u", p->row_group, p->row_index, p->row_parts);
         return PT_ERR_INVALID;
     }
+    if ((p->flags & PT_FLAG_REFERENCE_LIGHTS) && (p->flags & PT_FLAG_NEE)) {
+        set_error("PT_FLAG_REFERENCE_LIGHTS and PT_FLAG_NEE exclude each other");
+        return PT_ERR_INVALID;
+    }
     if ((p->flags & PT_FLAG_PROPAGATE_DIFFS) && !std::isfinite(p->diff_size)) {
         set_error("diff_size is not finite");
         return PT_ERR_INVALID;
@@ -419,6 +423,14 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
         bool emissive = m.kind == PT_MAT_LAMBERT && (m.emission[0] != 0.f || m.emission[1] != 0.f || m.emission[2] != 0.f);
         if (emissive && q.kind == PT_PRIM_PLANE) { set_error("primitive %u: an emissive plane has infinite area", k); return PT_ERR_UNSUPPORTED; }
         if (q.kind == PT_PRIM_SPHERE && !(q.radius > 0.)) { set_error("primitive %u: sphere radius must be positive", k); return PT_ERR_INVALID; }
+    }
+    if (d->n_area_lights && !d->area_lights) { set_error("area_lights missing"); return PT_ERR_INVALID; }
+    if (d->n_area_lights > 1) { set_error("more than one area light"); return PT_ERR_UNSUPPORTED; }
+    for (uint32_t k = 0; k < d->n_area_lights; ++k) {
+        const pt_area_light& al = d->area_lights[k];
+        bool finite = std::isfinite(al.radius);
+        for (int a = 0; a < 3; ++a) finite = finite && std::isfinite(al.center[a]) && std::isfinite(al.intensity[a]);
+        if (!finite || !(al.radius >= 0.)) { set_error("area light %u: centre, radius >= 0 and intensity must be finite", k); return PT_ERR_INVALID; }
     }
     int n_dev = 0;
     hipError_t dev_err = hipGetDeviceCount(&n_dev);
@@ -626,6 +638,13 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
         if (d->mats[i].kind != PT_MAT_LAMBERT) dv.mat_features |= 2u;
     }
     dv.light_area = acc;
+    dv.n_area_lights = d->n_area_lights;
+    for (int a = 0; a < 7; ++a) dv.area_light[a] = 0.;
+    if (d->n_area_lights) {
+        const pt_area_light& al = d->area_lights[0];
+        for (int a = 0; a < 3; ++a) { dv.area_light[a] = al.center[a]; dv.area_light[4 + a] = al.intensity[a]; }
+        dv.area_light[3] = al.radius;
+    }
     // scene.rs:38-42, hoisted out of Camera::ray
     H3 view{d->camera.view[0], d->camera.view[1], d->camera.view[2]};
     H3 up{d->camera.up[0], d->camera.up[1], d->camera.up[2]};
@@ -954,7 +973,7 @@ int pt_render_device(pt_scene* s, const pt_render_params* P_in, double* accum_de
     const uint32_t npix = tw * th;
     s->stats.samples += n_asked;
     if (npix == 0) return PT_OK;  // nothing of the tile on screen, or a row partition with more parts than row groups
-    const bool nee = (P->flags & PT_FLAG_NEE) != 0 && s->dev.n_lights > 0;
+    const bool nee = ptd::samples_lights(s->dev, P->flags);
     // differentials only feed texture filtering: without a texture (or a second vertex) nothing reads them
     const bool diffs = (P->flags & PT_FLAG_PROPAGATE_DIFFS) && (P->flags & PT_FLAG_USE_DIFFS) && s->n_texs > 0 &&
                        P->max_bounces > 0;
@@ -1051,7 +1070,7 @@ int pt_render_device_noalloc(pt_scene* s, const pt_render_params* P_in, double* 
 
     const uint32_t npix = (P->x1 - P->x0) * owned_rows(P);
     if (npix == 0) { s->stats.samples += n_asked; return PT_OK; }  // nothing on screen / an empty row partition
-    const bool nee = (P->flags & PT_FLAG_NEE) != 0 && s->dev.n_lights > 0;
+    const bool nee = ptd::samples_lights(s->dev, P->flags);
     const bool diffs = (P->flags & PT_FLAG_PROPAGATE_DIFFS) && (P->flags & PT_FLAG_USE_DIFFS) && s->n_texs > 0 &&
                        P->max_bounces > 0;
     // the frame jitters sit in front of the carved workspace

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/pt.h"
+
 namespace ptd {
 
 // ---- scene in HBM -------------------------------------------------------------------------
@@ -147,7 +149,18 @@ struct Scene {
     uint32_t n_cu;  // compute units of the device (size of a persistent launch)
     Camera cam;
     double background[3];
+    // lights.rs:37-40 AreaLight of PT_FLAG_REFERENCE_LIGHTS: centre, radius, intensity (n_area_lights 0 or 1)
+    double area_light[7];
+    uint32_t n_area_lights;
 };
+// A vertex draws a light sample (the NEE instantiations of the shade kernels): the build's next-event
+// estimation, or the reference's own direct-light path, which excludes it.
+__host__ __device__ inline bool reference_lights(const Scene& sc, uint32_t flags) {
+    return (flags & PT_FLAG_REFERENCE_LIGHTS) != 0 && sc.n_area_lights > 0;
+}
+__host__ __device__ inline bool samples_lights(const Scene& sc, uint32_t flags) {
+    return reference_lights(sc, flags) || ((flags & PT_FLAG_NEE) != 0 && sc.n_lights > 0);
+}
 
 // ---- ray / path queue (SoA, one entry per path in flight) -----------------------------------
 struct Queue {

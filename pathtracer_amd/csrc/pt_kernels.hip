@@ -169,7 +169,7 @@ static void launch_shade_t(bool nee, dim3 g, dim3 b, hipStream_t st, const Scene
 void launch_shade(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, Hits hits, Live live, Queue out,
                   Push out_push, ShadowQueue sq, Push sq_push, Sample3 ls, hipStream_t st) {
     if (!live.n) return;
-    bool nee = (fr.flags & PT_FLAG_NEE) != 0 && sc.n_lights > 0;
+    bool nee = samples_lights(sc, fr.flags);
     bool first = bounce == 0, last = bounce >= fr.max_bounces;
     dim3 g(blocks_for(live.n)), b(kBlock);
     if (last && !first && live.counts && sc.cull_last) {  // the queue after the cull: a few percent full
@@ -215,7 +215,7 @@ bool launch_path(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, Li
                  ShadowQueue sq, Push sq_push, Sample3 ls, Counters* ctr, hipStream_t st) {
     if (!path_fusable(sc, bounce)) return false;
     if (!live.n) return true;
-    bool nee = (fr.flags & PT_FLAG_NEE) != 0 && sc.n_lights > 0;
+    bool nee = samples_lights(sc, fr.flags);
     bool first = bounce == 0, last = bounce >= fr.max_bounces;
     // the variant launch_path_t picks: the scene-in-LDS kernel has its own workgroup size
     const bool lds = sc.bvh_depth <= 8 && !last && sc.lds_scene;

@@ -618,7 +618,8 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
         const Material& m = sc.mats[mat];
         D3 le = (SPEC && m.kind != PT_MAT_LAMBERT) ? mk(0., 0., 0.) : ld3(m.emission);  // microfacet.rs:33-35; specular: none
         add = T * le;  // main.rs:307
-        if (NEE && !FIRST && (le.x != 0. || le.y != 0. || le.z != 0.)) {
+        const bool ref_lights = NEE && reference_lights(sc, fr.flags);  // lights.rs as written: no MIS
+        if (NEE && !FIRST && !ref_lights && (le.x != 0. || le.y != 0. || le.z != 0.)) {
             // MIS weight of a BRDF-sampled hit on a light (balance heuristic)
             // triangles emit from both faces (main.rs:307 adds Le on any hit), spheres from outside
             // only (lights.rs:47-49)
@@ -666,7 +667,34 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
             } else if (!SPEC || m.kind == PT_MAT_LAMBERT) {
                 diffuse = TEX ? diffuse_of(sc, m, leaf, o, d, position, normal, fr, FIRST, pixel, s) : ld3(m.color);
             }
-            if (NEE && sc.n_lights) {
+            if (ref_lights) {
+                // EstimateDirect (lights.rs:110-137) over AreaLight::sample (lights.rs:42-62) and
+                // Sphere::sample_surface (lights.rs:70-78), at a Lambertian vertex (pt.h, PT_FLAG_REFERENCE_LIGHTS)
+                if (!SPEC || m.kind == PT_MAT_LAMBERT) {
+                    double r0, r1;
+                    uniform2(fr.seed, pixel, sample, bounce, STREAM_LIGHT, r0, r1);
+                    double z = 1. - 2. * r0;  // sample_sphere, lights.rs:7-15
+                    double rr = sqrt(fmax(0., 1. - z * z));
+                    double phi = 2. * PT_PI * r1;
+                    double sp, cp;
+                    sincos(phi, &sp, &cp);
+                    D3 unit_sample = mk(rr * cp, rr * sp, z);
+                    D3 light_pos = unit_sample * sc.area_light[3] + mk(sc.area_light[0], sc.area_light[1], sc.area_light[2]);
+                    const double light_pdf = 0.25 * PT_FRAC_1_PI;  // lights.rs:76, whatever the radius
+                    D3 diff = light_pos - position;
+                    D3 light_direction = normalize(diff);
+                    if (!(dot(unit_sample, -light_direction) < 0.)) {  // lights.rs:48-50
+                        D3 irradiance = mk(sc.area_light[4], sc.area_light[5], sc.area_light[6]) / dot(diff, diff);
+                        D3 f = diffuse * PT_FRAC_1_PI * fabs(dot(light_direction, normal));
+                        D3 Ld = f * irradiance / light_pdf;  // lights.rs:132-135
+                        r.s_c = T * Ld;
+                        r.s_d = light_direction;
+                        r.s_tmax = length(diff);  // lights.rs:52
+                        r.n_o = position;
+                        r.shadow = true;
+                    }
+                }
+            } else if (NEE && sc.n_lights) {
                 double r0, r1;
                 uniform2(fr.seed, pixel, sample, bounce, STREAM_LIGHT, r0, r1);
                 double target = r0 * sc.light_area;

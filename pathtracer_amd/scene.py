@@ -67,6 +67,7 @@ class Config:
     propagate_diffs: bool = False   # legacy reflect_diff / refract_diff, main.rs:192-281 (§8f N3)
     diff_size: float = 0.0          # --diff (main.rs:348)
     roughdiff: bool = False         # -p (main.rs:351)
+    reference_lights: bool = False  # lights.rs:42-78,110-137 as written, against SceneData.area_light
     spp_per_batch: int = 0
 
     @property
@@ -91,6 +92,8 @@ class Config:
             f |= L.PT_FLAG_PROPAGATE_DIFFS
         if self.roughdiff:
             f |= L.PT_FLAG_ROUGHDIFF
+        if self.reference_lights:
+            f |= L.PT_FLAG_REFERENCE_LIGHTS
         return f
 
     def params(self, sample_begin: int, sample_count: int, tile=None, rows=None) -> L.pt_render_params:
@@ -118,7 +121,7 @@ class SceneData:
     """
 
     def __init__(self, verts, tris, tri_material, mats, tri_uvs=None, textures=(), camera: Camera = None,
-                 background=(0.0, 0.0, 0.0), model_names=(), model_first_tri=(), prims=None):
+                 background=(0.0, 0.0, 0.0), model_names=(), model_first_tri=(), prims=None, area_light=None):
         self.verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
         self.tris = np.ascontiguousarray(tris, dtype=np.uint32).reshape(-1, 3)
         self.tri_material = np.ascontiguousarray(tri_material, dtype=np.uint32).reshape(-1)
@@ -133,6 +136,8 @@ class SceneData:
         self.bvh_tri_order = None
         # analytic spheres / planes (geometry/mod.rs:20-29), PRIM_DTYPE records; hit ids PT_PRIM_BASE + k
         self.prims = None if prims is None else np.ascontiguousarray(prims, dtype=PRIM_DTYPE).reshape(-1)
+        # lights.rs:37-40 AreaLight: (center, radius, intensity), the light of PT_FLAG_REFERENCE_LIGHTS
+        self.area_light = area_light
 
     @property
     def n_tris(self) -> int:
@@ -163,6 +168,14 @@ class SceneData:
         if self.prims is not None and len(self.prims):
             d.prims = C.cast(self.prims.ctypes.data, C.POINTER(L.pt_primitive))
             d.n_prims = self.prims.shape[0]
+        if self.area_light is not None:
+            center, radius, intensity = self.area_light
+            self._area_light = L.pt_area_light()
+            self._area_light.center[:] = [float(x) for x in center]
+            self._area_light.radius = float(radius)
+            self._area_light.intensity[:] = [float(x) for x in intensity]
+            d.area_lights = C.pointer(self._area_light)
+            d.n_area_lights = 1
         return d
 
 
