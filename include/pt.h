@@ -183,9 +183,10 @@ enum {
                                         * EstimateDirect has no caller in the reference; here it is evaluated at
                                         * every Lambertian vertex that is not the path's last, and
                                         * throughput * Ld is added to the sample (other materials: the
-                                        * reference's zero-vector BRDF call is defined for Lambertian only).  It is
-                                        * NOT an unbiased estimator of a sphere emitter (tests/test_lights.py
-                                        * states what it converges to).  Excludes PT_FLAG_NEE. */
+                                        * reference's zero-vector BRDF call is defined for Lambertian only).
+                                        * Unoccluded it converges to what a Lambertian sphere of radiance
+                                        * 2 intensity / radius^2 gives; under partial occlusion it does not
+                                        * (tests/test_lights.py measures both).  Excludes PT_FLAG_NEE. */
 };
 
 /* CONFIG of main.rs:320-379 plus the partitioning knobs of SURVEY.md §8e. */
