@@ -187,6 +187,11 @@ class Workload:
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc.get("traffic_bytes_per_launch"),
             "algorithmic_bytes_per_launch": round(bytes_per_launch),
         }
+        if hbm["traffic"]:
+            # what the memory system actually moved (counters) over the same live duration: below `achieved` where
+            # the caches serve part of the algorithmic bytes (the deep tree's upper levels), above it on re-reads
+            hbm["traffic_GBs"] = round(gbs(hbm["traffic"], avg_ms), 2)
+            hbm["traffic_frac"] = round(hbm["traffic_GBs"] / HBM_PEAK_GBS, 5)
         valu = None
         if pmc.get("valu_busy_cycles_per_launch"):
             # VALU issue: SIMD-cycles in which a vector instruction issues (SQ_ACTIVE_INST_VALU x 4, a count
@@ -290,6 +295,8 @@ def main():
                     help="N = 1: also time the other BASELINE configs for a few steps each")
     ap.add_argument("--config-steps", type=int, default=2)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true",
+                    help="skip the instrumented batches behind `roofline` (counter passes: only the timed kernels run)")
     args = ap.parse_args()
 
     # ---- N > 1 without a launcher: start the ranks ourselves, before anything here touches the GPU ------
@@ -347,7 +354,7 @@ def main():
     out = None
     if rank == 0:
         next_frame = (args.warmup + args.steps) * wk.spp * world
-        roofline = wk.roofline(st, samples_per_rank, next_frame)
+        roofline = None if args.no_roofline else wk.roofline(st, samples_per_rank, next_frame)
         # ---- CPU baseline: the oracle (C++ restatement, libm, f64) on this box's host cores ----
         cpu = None
         if args.cpu_seconds > 0 and world == 1:

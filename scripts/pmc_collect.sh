@@ -16,7 +16,7 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" \
            "FETCH_SIZE" "WRITE_SIZE" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_BUSY_avr GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout -s KILL 240 rocprofv3 --pmc $grp -d $OUT/p$i -o p --output-format csv -- python3 $ROOT/bench.py --configs none --cpu-seconds 0 "$@" > $OUT/p$i.log 2>&1
+  timeout -s KILL 240 rocprofv3 --pmc $grp -d $OUT/p$i -o p --output-format csv -- python3 $ROOT/bench.py --configs none --cpu-seconds 0 --no-roofline "$@" > $OUT/p$i.log 2>&1
   rc=$?
   echo "pass $i ($grp) rc=$rc"
   if [ $rc -ne 0 ]; then tail -3 $OUT/p$i.log; exit $rc; fi
