@@ -240,7 +240,41 @@ typedef struct pt_stats {
 
 typedef struct pt_scene pt_scene;
 
-/* ---- scene.rs:140-193 + bvh.rs:17-21: build the device-resident scene on HIP device `device_id` */
+/* How the library schedules the work of one scene.  No counterpart in the reference (its scheduling is rayon's,
+ * main.rs:409-432); every combination renders the same image (the tests render them against each other).  Fields
+ * are PT_OPT_DEFAULT (the library decides from the scene: what the measurements in DESIGN.md chose), 0 or 1;
+ * the counts are 0 for the default. */
+#define PT_OPT_DEFAULT (-1)
+typedef struct pt_scene_options {
+    uint32_t struct_size;    /* sizeof(pt_scene_options), set by pt_scene_options_init: lets the struct grow */
+    int8_t vote_primary;     /* traverse primary / secondary / shadow rays as vote-scheduled ranges of wave_rays */
+    int8_t vote_secondary;   /*   rays per wave instead of one ray per lane (default: deep trees, not primary) */
+    int8_t vote_shadow;
+    int8_t fuse;             /* extend + shade of a bounce in one kernel where its rays go one per lane */
+    int8_t fuse_shadow;      /* ... and the bounce's light sample traced in that kernel too (needs fuse) */
+    int8_t light_cull;       /* drop last-bounce rays that can reach no emitter (black background, few emitters) */
+    int8_t screen_cull;      /* clip a tile to the scene's screen bounds (black background) */
+    int8_t pipeline;         /* two batches in flight on two streams (default: deep trees) */
+    int8_t persistent;       /* persistent launch of the vote-scheduled traversal kernels */
+    int8_t eye_tables;       /* per-scene tables for rays from the eye (shallow trees of <= 65 536 triangles) */
+    int8_t lds_scene;        /* a tiny scene lives in LDS inside the fused kernel (needs eye_tables) */
+    int8_t reserved;
+    uint32_t wave_rays;      /* rays per vote-scheduled range: a power of two in 64..1024 (default 512) */
+    uint32_t bvh_max_leaf;   /* triangles per leaf of the library's own BVH build, 1..8 (default 2) */
+    uint32_t bvh_threads;    /* host threads of that build, 1..64 (default: the hardware's, at most 16) */
+} pt_scene_options;
+/* every field to its default */
+void pt_scene_options_init(pt_scene_options* options);
+/* ... then the overrides of the process environment, for tuning sweeps without a rebuild: PT_TRAV_VOTE_PRIMARY,
+ * PT_TRAV_VOTE, PT_TRAV_VOTE_SHADOW, PT_FUSE, PT_FUSE_SHADOW, PT_LIGHT_CULL, PT_SCREEN_CULL, PT_PIPELINE,
+ * PT_PERSISTENT, PT_EYE_TABLES, PT_LDS_SCENE = 0|1; PT_WAVE_RAYS, PT_BVH_LEAF, PT_BVH_THREADS = counts.  This is the
+ * only function of the library that reads the environment. */
+void pt_scene_options_from_env(pt_scene_options* options);
+
+/* ---- scene.rs:140-193 + bvh.rs:17-21: build the device-resident scene on HIP device `device_id`.
+ * pt_scene_create_ex takes the scheduling options of this scene (NULL = all defaults) and never reads the
+ * environment; pt_scene_create is pt_scene_create_ex with pt_scene_options_from_env's options. */
+int pt_scene_create_ex(const pt_scene_desc* desc, int device_id, const pt_scene_options* options, pt_scene** out);
 int pt_scene_create(const pt_scene_desc* desc, int device_id, pt_scene** out);
 void pt_scene_destroy(pt_scene* scene);
 /* introspection (host copies owned by the scene, valid until destroy) */
@@ -249,10 +283,11 @@ int pt_scene_get_bvh(const pt_scene* scene, const pt_bvh_node** nodes, uint32_t*
 
 /* ---- bvh.rs:17-21 `e_BVH::unanimated(8, ..)`: host-side binned-SAH build (the external crate
  * is not vendored).  nodes_out has room for `cap_nodes` (>= max(1, n_tris)) nodes,
- * order_out for n_tris ids.  max_leaf in 1..8. */
+ * order_out for n_tris ids.  max_leaf in 1..8.  n_threads: host threads of the build, 0 = the hardware's (at most
+ * 16); the tree is the same array whatever the count. */
 int pt_bvh_build(const float* verts, uint32_t n_verts, const uint32_t* tris, uint32_t n_tris,
                  uint32_t max_leaf, pt_bvh_node* nodes_out, uint32_t cap_nodes,
-                 uint32_t* n_nodes_out, uint32_t* order_out, uint32_t* max_depth_out);
+                 uint32_t* n_nodes_out, uint32_t* order_out, uint32_t* max_depth_out, uint32_t n_threads);
 
 /* ---- bvh.rs:17-21 when the host keeps its own builder (north_star: "BVH build in bvh.rs"): checks
  * everything the traversal kernels assume of a caller-supplied tree before pt_scene_create takes it

@@ -66,6 +66,13 @@ class pt_scene_desc(C.Structure):
                 ("area_lights", C.POINTER(pt_area_light)), ("n_area_lights", C.c_uint32)]
 
 
+class pt_scene_options(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32)] + [(n, C.c_int8) for n in (
+        "vote_primary", "vote_secondary", "vote_shadow", "fuse", "fuse_shadow", "light_cull", "screen_cull", "pipeline",
+        "persistent", "eye_tables", "lds_scene", "reserved")] + [
+        ("wave_rays", C.c_uint32), ("bvh_max_leaf", C.c_uint32), ("bvh_threads", C.c_uint32)]
+
+
 class pt_ray(C.Structure):
     _fields_ = [("o", C.c_double * 3), ("d", C.c_double * 3), ("t_min", C.c_double), ("t_max", C.c_double)]
 
@@ -99,10 +106,13 @@ _P = C.POINTER
 _vp = C.c_void_p
 PROTOTYPES = {
     "pt_scene_create": (C.c_int, [_P(pt_scene_desc), C.c_int, _P(_vp)]),
+    "pt_scene_create_ex": (C.c_int, [_P(pt_scene_desc), C.c_int, _P(pt_scene_options), _P(_vp)]),
+    "pt_scene_options_init": (None, [_P(pt_scene_options)]),
+    "pt_scene_options_from_env": (None, [_P(pt_scene_options)]),
     "pt_scene_destroy": (None, [_vp]),
     "pt_scene_get_bvh": (C.c_int, [_vp, _P(_P(pt_bvh_node)), _P(C.c_uint32), _P(_P(C.c_uint32)), _P(C.c_uint32)]),
     "pt_bvh_build": (C.c_int, [_P(C.c_float), C.c_uint32, _P(C.c_uint32), C.c_uint32, C.c_uint32,
-                               _P(pt_bvh_node), C.c_uint32, _P(C.c_uint32), _P(C.c_uint32), _P(C.c_uint32)]),
+                               _P(pt_bvh_node), C.c_uint32, _P(C.c_uint32), _P(C.c_uint32), _P(C.c_uint32), C.c_uint32]),
     "pt_bvh_validate": (C.c_int, [_P(pt_bvh_node), C.c_uint32, _P(C.c_uint32), C.c_uint32, _P(C.c_uint32)]),
     "pt_trace_closest": (C.c_int, [_vp, _P(pt_ray), C.c_size_t, _P(C.c_uint32), _P(C.c_double)]),
     "pt_generate_rays": (C.c_int, [_vp, _P(pt_render_params), C.c_uint64, _P(pt_ray)]),

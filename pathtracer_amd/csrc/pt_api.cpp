@@ -204,26 +204,19 @@ H3 hneg(H3 a) { return {-a.x, -a.y, -a.z}; }
 
 // Traversal scheduling of a scene (pt_traverse.hip.h trace_range_vote / traverse).  Defaults from the
 // sweeps recorded in DESIGN.md "Traversal scheduling": primary rays one ray per lane; secondary and
-// shadow rays vote-scheduled over ranges of 256 rays when the tree is deeper than 8 levels (scenes
-// from ~500 triangles up).  Tuning runs and tests override it through the environment, read when
-// the scene is created: PT_TRAV_VOTE_PRIMARY / PT_TRAV_VOTE / PT_TRAV_VOTE_SHADOW = 0|1,
-// PT_WAVE_RAYS = 64..1024 (power of two).
-void resolve_scheduling(ptd::Scene& dv) {
-    auto flag = [](const char* name, bool dflt) {
-        const char* e = getenv(name);
-        return (uint8_t)((e && *e) ? atoi(e) != 0 : dflt);
-    };
+// shadow rays vote-scheduled over ranges of 512 rays when the tree is deeper than 8 levels (scenes
+// from ~500 triangles up).  pt_scene_options overrides each.
+inline bool opt(int8_t v, bool dflt) { return v < 0 ? dflt : v != 0; }
+bool valid_wave_rays(uint32_t r) { return r >= 64 && r <= ptd::kSegAlign && (r & (r - 1)) == 0; }
+void resolve_scheduling(ptd::Scene& dv, const pt_scene_options& o) {
     const bool deep = dv.bvh_depth > 8;
-    dv.vote_primary = flag("PT_TRAV_VOTE_PRIMARY", false);
-    dv.vote_secondary = flag("PT_TRAV_VOTE", deep);
-    dv.vote_shadow = flag("PT_TRAV_VOTE_SHADOW", deep);
-    dv.fuse = flag("PT_FUSE", true);
-    dv.fuse_shadow = flag("PT_FUSE_SHADOW", true) && dv.fuse;
-    dv.wave_rays = 512;  // (128 / 256 / 512 / 1024 -> 8.73 / 9.17 / 9.29 / 9.3 Gsamples/s on the 10 M-triangle scene)
-    if (const char* e = getenv("PT_WAVE_RAYS")) {
-        uint32_t r = (uint32_t)atoi(e);
-        if (r >= 64 && r <= ptd::kSegAlign && (r & (r - 1)) == 0) dv.wave_rays = r;
-    }
+    dv.vote_primary = opt(o.vote_primary, false);
+    dv.vote_secondary = opt(o.vote_secondary, deep);
+    dv.vote_shadow = opt(o.vote_shadow, deep);
+    dv.fuse = opt(o.fuse, true);
+    dv.fuse_shadow = opt(o.fuse_shadow, true) && dv.fuse;
+    // (128 / 256 / 512 / 1024 -> 8.73 / 9.17 / 9.29 / 9.3 Gsamples/s on the 10 M-triangle scene)
+    dv.wave_rays = o.wave_rays ? o.wave_rays : 512;
 }
 
 template <class T>
@@ -362,7 +355,7 @@ extern "C" {
 
 int pt_bvh_build(const float* verts, uint32_t n_verts, const uint32_t* tris, uint32_t n_tris, uint32_t max_leaf,
                  pt_bvh_node* nodes_out, uint32_t cap_nodes, uint32_t* n_nodes_out, uint32_t* order_out,
-                 uint32_t* max_depth_out) {
+                 uint32_t* max_depth_out, uint32_t n_threads) {
     if ((n_tris && (!verts || !tris)) || !nodes_out || !n_nodes_out || (n_tris && !order_out)) {
         set_error("null argument");
         return PT_ERR_INVALID;
@@ -370,7 +363,7 @@ int pt_bvh_build(const float* verts, uint32_t n_verts, const uint32_t* tris, uin
     std::vector<pt_bvh_node> nodes;
     std::vector<uint32_t> order;
     uint32_t depth = 0;
-    int rc = pth::bvh_build(verts, n_verts, tris, n_tris, max_leaf, nodes, order, depth);
+    int rc = pth::bvh_build(verts, n_verts, tris, n_tris, max_leaf, nodes, order, depth, n_threads);
     if (rc != PT_OK) { set_error("bvh build failed (bad index, non-finite vertex or max_leaf)"); return rc; }
     if (nodes.size() > cap_nodes) { set_error("nodes_out too small: need %zu", nodes.size()); return PT_ERR_INVALID; }
     std::memcpy(nodes_out, nodes.data(), nodes.size() * sizeof(pt_bvh_node));
@@ -396,9 +389,64 @@ int pt_bvh_validate(const pt_bvh_node* nodes, uint32_t n_nodes, const uint32_t* 
     return PT_OK;
 }
 
+void pt_scene_options_init(pt_scene_options* o) {
+    if (!o) return;
+    memset(o, 0, sizeof *o);
+    o->struct_size = (uint32_t)sizeof *o;
+    o->vote_primary = o->vote_secondary = o->vote_shadow = o->fuse = o->fuse_shadow = o->light_cull = o->screen_cull =
+        o->pipeline = o->persistent = o->eye_tables = o->lds_scene = PT_OPT_DEFAULT;
+}
+
+void pt_scene_options_from_env(pt_scene_options* o) {
+    if (!o) return;
+    pt_scene_options_init(o);
+    auto flag = [](const char* name, int8_t& v) {
+        const char* e = getenv(name);
+        if (e && *e) v = atoi(e) != 0;
+    };
+    auto count = [](const char* name, uint32_t& v) {
+        const char* e = getenv(name);
+        if (e && *e && atoi(e) > 0) v = (uint32_t)atoi(e);
+    };
+    flag("PT_TRAV_VOTE_PRIMARY", o->vote_primary);
+    flag("PT_TRAV_VOTE", o->vote_secondary);
+    flag("PT_TRAV_VOTE_SHADOW", o->vote_shadow);
+    flag("PT_FUSE", o->fuse);
+    flag("PT_FUSE_SHADOW", o->fuse_shadow);
+    flag("PT_LIGHT_CULL", o->light_cull);
+    flag("PT_SCREEN_CULL", o->screen_cull);
+    flag("PT_PIPELINE", o->pipeline);
+    flag("PT_PERSISTENT", o->persistent);
+    flag("PT_EYE_TABLES", o->eye_tables);
+    flag("PT_LDS_SCENE", o->lds_scene);
+    count("PT_WAVE_RAYS", o->wave_rays);
+    if (!valid_wave_rays(o->wave_rays)) o->wave_rays = 0;  // a sweep's bad value falls back to the default
+    count("PT_BVH_LEAF", o->bvh_max_leaf);
+    count("PT_BVH_THREADS", o->bvh_threads);
+}
+
 int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
+    pt_scene_options o;
+    pt_scene_options_from_env(&o);
+    return pt_scene_create_ex(d, device_id, &o, out);
+}
+
+int pt_scene_create_ex(const pt_scene_desc* d, int device_id, const pt_scene_options* options, pt_scene** out) {
     if (!d || !out) { set_error("null argument"); return PT_ERR_INVALID; }
     *out = nullptr;
+    pt_scene_options o;
+    pt_scene_options_init(&o);
+    if (options) {
+        if (options->struct_size != sizeof o) {
+            set_error("pt_scene_options::struct_size is %u, this library's is %zu (call pt_scene_options_init first)",
+                      options->struct_size, sizeof o);
+            return PT_ERR_INVALID;
+        }
+        o = *options;
+    }
+    if (o.wave_rays && !valid_wave_rays(o.wave_rays)) { set_error("wave_rays must be a power of two in 64..%u", ptd::kSegAlign); return PT_ERR_INVALID; }
+    if (o.bvh_max_leaf > 8) { set_error("bvh_max_leaf must be in 1..8"); return PT_ERR_INVALID; }
+    if (o.bvh_threads > 64) { set_error("bvh_threads must be in 1..64"); return PT_ERR_INVALID; }
     if (d->n_tris && (!d->verts || !d->tris)) { set_error("verts/tris missing"); return PT_ERR_INVALID; }
     if (d->n_tris && d->n_mats == 0) { set_error("scene has triangles but no materials"); return PT_ERR_INVALID; }
     if ((d->n_mats && !d->mats) || (d->n_texs && !d->texs)) { set_error("mats/texs missing"); return PT_ERR_INVALID; }
@@ -456,9 +504,8 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
     } else {
         // leaves of at most 2 triangles (a quad): measured against 1/3/4/8 on both bench scenes
         // (CornellBox 13.3/13.6/11.6/11.5, 10 M triangles 3.03/3.42/3.16/2.84 Gsamples/s; 2: 13.6/3.43)
-        uint32_t max_leaf = 2;
-        if (const char* e = getenv("PT_BVH_LEAF")) max_leaf = (uint32_t)atoi(e);
-        int rc = pth::bvh_build(d->verts, d->n_verts, d->tris, d->n_tris, max_leaf, s->nodes, s->order, s->depth);
+        const uint32_t max_leaf = o.bvh_max_leaf ? o.bvh_max_leaf : 2;
+        int rc = pth::bvh_build(d->verts, d->n_verts, d->tris, d->n_tris, max_leaf, s->nodes, s->order, s->depth, o.bvh_threads);
         if (rc != PT_OK) { set_error("bvh build failed (non-finite vertex?)"); return rc; }
     }
     {   // the traversal kernels trust the tree (indices, leaf runs, depth <= their LDS stack): check it all
@@ -612,26 +659,24 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
     dv.emissive = s->d_emissive.as<ptd::EmitTri>();
     dv.n_emissive = (uint32_t)emissive.size();
     // last-bounce cull (pt_shade.hip.h may_reach_emitter): needs a black background and emitters that
-    // are a few triangles; PT_LIGHT_CULL=0 switches it off (tests render both ways)
+    // are a few triangles; pt_scene_options::light_cull = 0 switches it off (tests render both ways)
     dv.cull_last = !emissive_prim && emissive.size() <= ptd::kMaxCullEmitters && d->background[0] == 0. &&
-                   d->background[1] == 0. && d->background[2] == 0.;
-    if (const char* e = getenv("PT_LIGHT_CULL")) dv.cull_last = dv.cull_last && atoi(e) != 0;
+                   d->background[1] == 0. && d->background[2] == 0. && opt(o.light_cull, true);
     dv.prims = s->d_prims.as<ptd::Prim>();
     dv.n_prims = d->n_prims;
     dv.n_nodes = d->n_tris ? (uint32_t)s->nodes.size() : 0u;
     dv.n_tris = d->n_tris;
     dv.n_lights = (uint32_t)lights.size();
     dv.bvh_depth = s->depth;
-    resolve_scheduling(dv);
+    resolve_scheduling(dv, o);
     {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device_id));
         dv.n_cu = (uint32_t)prop.multiProcessorCount;
     }
-    if (const char* e = getenv("PT_PERSISTENT")) s->persistent = atoi(e) != 0;
-    if (const char* e = getenv("PT_SCREEN_CULL")) s->screen_cull = atoi(e) != 0;
-    s->pipeline = dv.bvh_depth > 8;
-    if (const char* e = getenv("PT_PIPELINE")) s->pipeline = atoi(e) != 0;  // tuning / tests, like the above
+    s->persistent = opt(o.persistent, s->persistent);
+    s->screen_cull = opt(o.screen_cull, s->screen_cull);
+    s->pipeline = opt(o.pipeline, dv.bvh_depth > 8);
     dv.mat_features = 0;
     for (uint32_t i = 0; i < d->n_mats; ++i) {
         if (d->mats[i].tex >= 0) dv.mat_features |= 1u;
@@ -669,8 +714,7 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
     HIP_TRY(hipDeviceSynchronize());  // d_emissive_leaf goes out of scope with this function
     dv.eye_nodes = nullptr;
     dv.eye_tris = nullptr;
-    const char* eye_env = getenv("PT_EYE_TABLES");
-    if (dv.n_nodes && s->depth <= 8 && d->n_tris <= ptd::kEyeTableMaxTris && !(eye_env && atoi(eye_env) == 0)) {
+    if (dv.n_nodes && s->depth <= 8 && d->n_tris <= ptd::kEyeTableMaxTris && opt(o.eye_tables, true)) {
         HIP_TRY(s->d_eye_nodes.alloc(s->nodes.size() * sizeof(ptd::EyeNode)));
         HIP_TRY(s->d_eye_tris.alloc((size_t)d->n_tris * sizeof(ptd::EyeTri)));
         ptd::launch_build_eye_tables(dv, s->d_eye_nodes.as<ptd::EyeNode>(), s->d_eye_tris.as<ptd::EyeTri>(), nullptr);
@@ -679,8 +723,7 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
     }
     dv.n_mats = d->n_mats;
     dv.lds_scene = dv.eye_nodes && dv.n_nodes <= (uint32_t)ptd::kLdsScene && d->n_tris <= (uint32_t)ptd::kLdsScene &&
-                   d->n_mats <= (uint32_t)ptd::kLdsMats && d->n_prims == 0;
-    if (const char* e = getenv("PT_LDS_SCENE")) dv.lds_scene = dv.lds_scene && atoi(e) != 0;
+                   d->n_mats <= (uint32_t)ptd::kLdsMats && d->n_prims == 0 && opt(o.lds_scene, true);
     HIP_TRY(hipDeviceSynchronize());
     for (int a = 0; a < 3; ++a) dv.background[a] = d->background[a];
 

@@ -258,17 +258,15 @@ inline float round_up(double x) {
 }  // namespace
 
 int bvh_build(const float* verts, uint32_t n_verts, const uint32_t* tris, uint32_t n_tris, uint32_t max_leaf,
-              std::vector<pt_bvh_node>& out_nodes, std::vector<uint32_t>& out_order, uint32_t& out_depth) {
+              std::vector<pt_bvh_node>& out_nodes, std::vector<uint32_t>& out_order, uint32_t& out_depth, uint32_t threads) {
     if (max_leaf < 1 || max_leaf > 8) return PT_ERR_INVALID;
     if (n_tris >= (1u << 28)) return PT_ERR_UNSUPPORTED;  // leaf code keeps `first` in 28 bits
     out_nodes.clear();
     out_order.clear();
     out_depth = 0;
     if (n_tris == 0) return PT_OK;
-    auto T0 = std::chrono::steady_clock::now(); auto lap=[&](const char* w){ if(getenv("PT_BVH_TIMING")){auto t=std::chrono::steady_clock::now(); fprintf(stderr,"bvh %s %.3f s\n",w,std::chrono::duration<double>(t-T0).count()); T0=t;} };
     std::vector<Ref> refs(n_tris);
-    uint32_t n_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-    if (const char* e = getenv("PT_BVH_THREADS")) n_threads = (uint32_t)std::max(1, std::min(64, atoi(e)));
+    uint32_t n_threads = threads ? std::min(64u, threads) : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     if (n_tris < (1u << 16)) n_threads = 1;
     double max_abs = 0.;
     {
@@ -300,7 +298,6 @@ int bvh_build(const float* verts, uint32_t n_verts, const uint32_t* tris, uint32
             max_abs = std::max(max_abs, pmax[t]);
         }
     }
-    lap("refs");
     Builder b(refs, max_leaf);
     if (n_threads > 1) {
         std::vector<Pending> pending;
@@ -310,7 +307,6 @@ int bvh_build(const float* verts, uint32_t n_verts, const uint32_t* tris, uint32
         b.cut = std::max(n_tris / (8 * n_threads), 4096u);
         b.pending = &pending;
         b.build(0, n_tris, 0);
-        lap("top");
         std::vector<Builder> subs;
         subs.reserve(pending.size());
         for (size_t i = 0; i < pending.size(); ++i) subs.emplace_back(refs, max_leaf);
@@ -325,7 +321,6 @@ int bvh_build(const float* verts, uint32_t n_verts, const uint32_t* tris, uint32
         for (uint32_t t = 1; t < n_threads; ++t) pool.emplace_back(work);
         work();
         for (auto& t : pool) t.join();
-        lap("subtrees");
         std::vector<size_t> off(pending.size() + 1, b.nodes.size());
         for (size_t i = 0; i < pending.size(); ++i) off[i + 1] = off[i] + subs[i].nodes.size();
         b.nodes.resize(off[pending.size()]);
@@ -351,8 +346,6 @@ int bvh_build(const float* verts, uint32_t n_verts, const uint32_t* tris, uint32
         b.nodes.reserve((size_t)n_tris * 2 / max_leaf + 16);
         b.build(0, n_tris, 0);
     }
-
-    lap("splice");
     out_order.resize(n_tris);
     for (uint32_t i = 0; i < n_tris; ++i) out_order[i] = refs[i].id;
 
@@ -403,7 +396,6 @@ int bvh_build(const float* verts, uint32_t n_verts, const uint32_t* tris, uint32
         node.child[1] = r.left >= 0 ? out_index[n.right] : leaf_code(r);
         out_nodes[out_index[i]] = node;
     }
-    lap("flatten");
     out_depth = b.max_depth;
     return PT_OK;
 }

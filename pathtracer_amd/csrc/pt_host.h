@@ -27,7 +27,7 @@ const char* last_error();
 
 // pt_bvh.cpp
 int bvh_build(const float* verts, uint32_t n_verts, const uint32_t* tris, uint32_t n_tris, uint32_t max_leaf,
-              std::vector<pt_bvh_node>& out_nodes, std::vector<uint32_t>& out_order, uint32_t& out_depth);
+              std::vector<pt_bvh_node>& out_nodes, std::vector<uint32_t>& out_order, uint32_t& out_depth, uint32_t n_threads = 0);
 int bvh_collapse4(const std::vector<pt_bvh_node>& nodes2, uint32_t budget, std::vector<pt_bvh_node4>& out, uint32_t& need_out);
 void bvh_widen(std::vector<pt_bvh_node>& nodes, const float* verts, uint32_t n_verts);
 int bvh_validate(const pt_bvh_node* nodes, uint32_t n_nodes, const uint32_t* order, uint32_t n_tris,

@@ -207,7 +207,7 @@ def load_obj(obj_name: str, glossy: bool = False, textures: bool = False, specul
     return SceneData(verts, tris, tmat, mats, uvs, texs, model_names=names, model_first_tri=first)
 
 
-def bvh_build(verts: np.ndarray, tris: np.ndarray, max_leaf: int = 4):
+def bvh_build(verts: np.ndarray, tris: np.ndarray, max_leaf: int = 4, threads: int = 0):
     """bvh.rs:17-21 stand-in: host-side binned-SAH build. Returns (nodes, tri_order, depth)."""
     verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
     tris = np.ascontiguousarray(tris, dtype=np.uint32).reshape(-1, 3)
@@ -217,7 +217,7 @@ def bvh_build(verts: np.ndarray, tris: np.ndarray, max_leaf: int = 4):
     n_nodes, depth = C.c_uint32(), C.c_uint32()
     L.check(L.lib.pt_bvh_build(_ptr(verts, C.c_float), verts.shape[0], _ptr(tris, C.c_uint32), nt, max_leaf,
                                C.cast(nodes.ctypes.data, C.POINTER(L.pt_bvh_node)), nodes.shape[0],
-                               C.byref(n_nodes), _ptr(order, C.c_uint32), C.byref(depth)))
+                               C.byref(n_nodes), _ptr(order, C.c_uint32), C.byref(depth), threads))
     return nodes[: n_nodes.value].copy(), order[:nt].copy(), depth.value
 
 
@@ -233,12 +233,23 @@ def make_rays(origins, directions, t_min: float = 1e-5, t_max: float = np.finfo(
 class Scene:
     """scene.rs:13-18: the device-resident scene (BVH + triangles + materials + textures + camera)."""
 
-    def __init__(self, data: SceneData, device: int = 0):
+    def __init__(self, data: SceneData, device: int = 0, options: Optional[dict] = None):
+        """``options``: pt_scene_options fields by name (the rest stay at their defaults; the environment is not
+        read).  None = pt_scene_create, whose options come from the PT_* environment of tuning sweeps."""
         self.data = data
         self.device = device
         self._h = C.c_void_p()
         d = data.desc()
-        L.check(L.lib.pt_scene_create(C.byref(d), device, C.byref(self._h)))
+        if options is None:
+            L.check(L.lib.pt_scene_create(C.byref(d), device, C.byref(self._h)))
+        else:
+            o = L.pt_scene_options()
+            L.lib.pt_scene_options_init(C.byref(o))
+            for k, v in options.items():
+                if k not in dict(o._fields_) or k in ("struct_size", "reserved"):
+                    raise ValueError(f"unknown scene option {k!r}")
+                setattr(o, k, int(v))
+            L.check(L.lib.pt_scene_create_ex(C.byref(d), device, C.byref(o), C.byref(self._h)))
 
     # -- reference constructors ----------------------------------------------------------------
     @classmethod

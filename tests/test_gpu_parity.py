@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import pathtracer_amd as pt
+from pathtracer_amd import _lib as L
 import oracle_lib as O
 from conftest import record_parity
 
@@ -252,6 +253,47 @@ def test_caller_supplied_bvh_and_validation(gpu):
 # ---- traversal scheduling: both schedulers (vote-scheduled ranges / one ray per lane) on every scene -----
 FORCE_VOTE = dict(PT_TRAV_VOTE="1", PT_TRAV_VOTE_PRIMARY="1", PT_TRAV_VOTE_SHADOW="1", PT_WAVE_RAYS="128")
 FORCE_LANE = dict(PT_TRAV_VOTE="0", PT_TRAV_VOTE_PRIMARY="0", PT_TRAV_VOTE_SHADOW="0")
+
+
+def test_scene_options_select_the_same_variants_as_the_environment(gpu, monkeypatch):
+    # pt_scene_create_ex: the per-scene API for what the PT_* environment switches do for sweeps.  Each variant
+    # renders the same bytes as the default scene, and takes the path the matching environment switch takes
+    # (kernel launch counts by kind are the fingerprint of the path).
+    data = pt.scene_data("Test")
+    default = pt.Scene(data, gpu, options={})
+    cfg = pt.Config(width=160, height=90, samples_pr_pixel=4, bounces=2, seed=6, nee=True)
+
+    def fingerprint(scene):
+        scene.reset_stats()
+        scene.set_profiling(1)
+        img = scene.render(cfg)
+        st = scene.stats()
+        scene.set_profiling(0)
+        return img.tobytes(), tuple(st["kernel"][k]["launches"] for k in L.KERNEL_NAMES)
+
+    want, base_launches = fingerprint(default)
+    variants = (
+        (dict(fuse=0), dict(PT_FUSE="0")),
+        (dict(fuse_shadow=0), dict(PT_FUSE_SHADOW="0")),
+        (dict(vote_primary=1, vote_secondary=1, vote_shadow=1, wave_rays=128), FORCE_VOTE),
+        (dict(lds_scene=0), dict(PT_LDS_SCENE="0")),
+        (dict(eye_tables=0), dict(PT_EYE_TABLES="0")),
+        (dict(light_cull=0, screen_cull=0, persistent=0), dict(PT_LIGHT_CULL="0", PT_SCREEN_CULL="0", PT_PERSISTENT="0")),
+        (dict(pipeline=1, bvh_max_leaf=4, bvh_threads=2), dict(PT_PIPELINE="1", PT_BVH_LEAF="4", PT_BVH_THREADS="2")),
+    )
+    differ = 0
+    for options, env in variants:
+        got, launches = fingerprint(pt.Scene(data, gpu, options=options))
+        assert got == want, options
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        by_env, env_launches = fingerprint(pt.Scene(data, gpu))           # pt_scene_create: options from the environment
+        assert fingerprint(pt.Scene(data, gpu, options={}))[1] == base_launches   # ..._ex never reads it
+        for k in env:
+            monkeypatch.delenv(k)
+        assert by_env == want and env_launches == launches, options
+        differ += launches != base_launches
+    assert differ >= 2                                       # unfused and vote-scheduled paths launch other kernels
 
 
 @pytest.mark.parametrize("wave_rays", ["64", "128", "1024"])

@@ -37,6 +37,36 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(L.pt_material) == 40
     assert C.sizeof(L.pt_render_params) == 80
     assert C.sizeof(L.pt_camera) == 80
+    assert C.sizeof(L.pt_scene_options) == 28
+    assert C.sizeof(L.pt_area_light) == 56
+
+
+def test_scene_options_defaults_environment_and_validation(monkeypatch):
+    o = L.pt_scene_options()
+    L.lib.pt_scene_options_init(C.byref(o))
+    flags = [n for n, t in L.pt_scene_options._fields_ if t is C.c_int8 and n != "reserved"]
+    assert o.struct_size == 28 and all(getattr(o, n) == -1 for n in flags)
+    assert (o.wave_rays, o.bvh_max_leaf, o.bvh_threads, o.reserved) == (0, 0, 0, 0)
+    # the environment is read by pt_scene_options_from_env alone (the sweeps' hook, what pt_scene_create uses)
+    for k, v in (("PT_FUSE", "0"), ("PT_TRAV_VOTE", "1"), ("PT_WAVE_RAYS", "128"), ("PT_BVH_LEAF", "4"), ("PT_LDS_SCENE", "0")):
+        monkeypatch.setenv(k, v)
+    L.lib.pt_scene_options_from_env(C.byref(o))
+    assert (o.fuse, o.vote_secondary, o.wave_rays, o.bvh_max_leaf, o.lds_scene) == (0, 1, 128, 4, 0)
+    assert o.vote_primary == -1 and o.pipeline == -1
+    monkeypatch.setenv("PT_WAVE_RAYS", "100")               # not a power of two: the sweep falls back to the default
+    L.lib.pt_scene_options_from_env(C.byref(o))
+    assert o.wave_rays == 0
+    # bad options are refused before any device is touched
+    data = pt.scene_data("CornellBox")
+    for bad, why in ((dict(wave_rays=100), "wave_rays"), (dict(bvh_max_leaf=9), "bvh_max_leaf"), (dict(bvh_threads=65), "bvh_threads")):
+        with pytest.raises(pt.PtError, match=why):
+            pt.Scene(data, options=bad)
+    with pytest.raises(ValueError):
+        pt.Scene(data, options=dict(no_such_option=1))
+    d, h = data.desc(), C.c_void_p()
+    o.struct_size = 12
+    assert L.lib.pt_scene_create_ex(C.byref(d), 0, C.byref(o), C.byref(h)) == L.PT_ERR_INVALID
+    assert b"struct_size" in L.lib.pt_last_error()
 
 
 @pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU failure mode")
@@ -272,16 +302,15 @@ def test_checkpoint_roundtrip_and_damage(tmp_path):
         pt.load_checkpoint(str(tmp_path / "missing.ckpt"))
 
 
-def test_parallel_bvh_build_is_independent_of_thread_count(monkeypatch):
+def test_parallel_bvh_build_is_independent_of_thread_count():
     # the 10 M-triangle scene is built by worker threads; the tree must be the same
     # array whatever the thread count (serial std::partition vs. the stable parallel partition,
     # subtree splicing)
     from pathtracer_amd.synthetic import heightfield_box
     data = heightfield_box(cells=260)               # 135,210 triangles: above the parallel threshold
     out = []
-    for threads in ("1", "2", "7"):
-        monkeypatch.setenv("PT_BVH_THREADS", threads)
-        nodes, order, depth = pt.bvh_build(data.verts, data.tris)
+    for threads in (1, 2, 7):
+        nodes, order, depth = pt.bvh_build(data.verts, data.tris, threads=threads)
         out.append((nodes.tobytes(), order.tobytes(), depth))
     assert out[0] == out[1] == out[2]
     assert sorted(np.frombuffer(out[0][1], np.uint32).tolist()) == list(range(data.n_tris))
