@@ -9,6 +9,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <exception>
 #include <new>
 #include <string>
 #include <vector>
@@ -363,7 +364,13 @@ int pt_bvh_build(const float* verts, uint32_t n_verts, const uint32_t* tris, uin
     std::vector<pt_bvh_node> nodes;
     std::vector<uint32_t> order;
     uint32_t depth = 0;
-    int rc = pth::bvh_build(verts, n_verts, tris, n_tris, max_leaf, nodes, order, depth, n_threads);
+    int rc;
+    try {
+        rc = pth::bvh_build(verts, n_verts, tris, n_tris, max_leaf, nodes, order, depth, n_threads);
+    } catch (const std::bad_alloc&) {
+        set_error("out of host memory while building the BVH");
+        return PT_ERR_NOMEM;
+    }
     if (rc != PT_OK) { set_error("bvh build failed (bad index, non-finite vertex or max_leaf)"); return rc; }
     if (nodes.size() > cap_nodes) { set_error("nodes_out too small: need %zu", nodes.size()); return PT_ERR_INVALID; }
     std::memcpy(nodes_out, nodes.data(), nodes.size() * sizeof(pt_bvh_node));
@@ -378,9 +385,16 @@ int pt_bvh_validate(const pt_bvh_node* nodes, uint32_t n_nodes, const uint32_t* 
     if ((n_tris && (!nodes || !tri_order))) { set_error("null argument"); return PT_ERR_INVALID; }
     std::string why;
     uint32_t depth = 0;
-    int rc = pth::bvh_validate(nodes, n_nodes, tri_order, n_tris, (uint32_t)ptd::kStackDepth, depth, why);
+    std::vector<uint8_t> seen;
+    int rc;
+    try {
+        rc = pth::bvh_validate(nodes, n_nodes, tri_order, n_tris, (uint32_t)ptd::kStackDepth, depth, why);
+        seen.assign(n_tris, 0);
+    } catch (const std::bad_alloc&) {
+        set_error("out of host memory while validating the BVH");
+        return PT_ERR_NOMEM;
+    }
     if (rc != PT_OK) { set_error("invalid BVH: %s", why.c_str()); return rc; }
-    std::vector<uint8_t> seen(n_tris, 0);
     for (uint32_t i = 0; i < n_tris; ++i) {
         if (seen[tri_order[i]]) { set_error("invalid BVH: triangle %u listed twice", tri_order[i]); return PT_ERR_INVALID; }
         seen[tri_order[i]] = 1;
@@ -431,7 +445,20 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
     return pt_scene_create_ex(d, device_id, &o, out);
 }
 
+static int scene_create_impl(const pt_scene_desc* d, int device_id, const pt_scene_options* options, pt_scene** out);
+// No exception crosses the C ABI: a scene of 10 M triangles needs ~2 GB of host memory while it is built.
 int pt_scene_create_ex(const pt_scene_desc* d, int device_id, const pt_scene_options* options, pt_scene** out) {
+    try {
+        return scene_create_impl(d, device_id, options, out);
+    } catch (const std::bad_alloc&) {
+        set_error("out of host memory while building the scene");
+        return PT_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        set_error("scene creation failed: %s", e.what());
+        return PT_ERR_INVALID;
+    }
+}
+static int scene_create_impl(const pt_scene_desc* d, int device_id, const pt_scene_options* options, pt_scene** out) {
     if (!d || !out) { set_error("null argument"); return PT_ERR_INVALID; }
     *out = nullptr;
     pt_scene_options o;

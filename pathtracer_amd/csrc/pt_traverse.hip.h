@@ -172,16 +172,17 @@ __device__ __forceinline__ void prims_closest(const Scene& sc, D3 o, D3 d, doubl
         t_max = t;
     }
 }
-#ifdef PT_DEBUG_TAIL
+#ifdef PT_DEBUG_TAIL  // diagnostic build only (scripts/tail_probe.py): start / end clock of every persistent extend wave
 __device__ unsigned long long g_dbg_tail[16384];
 extern "C" int pt_debug_tail(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_tail), sizeof(unsigned long long) * 16384);
 }
 #endif
 constexpr int kDone = (int)0x80000000;
-// The LDS stack of a traversal holds DEPTH entries and DEPTH is instantiated from the scene's tree
-// depth (launchers: 8 / 16 / 32 >= Scene::bvh_depth; bvh_validate refuses deeper trees), so a push
-// can never find the stack full.  A build with -DPT_DEBUG_CHECKS counts any push that does, instead
+// The stack of a traversal can never be found full: a two-child tree of depth <= 8 gets 8 LDS entries,
+// anything deeper is walked through its four-wide collapse, whose need bvh_collapse4 bounds by
+// construction at kWideStack (kWideLds in LDS + kWideSpill private); bvh_validate refuses trees deeper
+// than kStackDepth before either.  A build with -DPT_DEBUG_CHECKS counts any push that does, instead
 // of trusting that argument: pt_debug_stack_overflows() must read 0 after any render.
 #ifdef PT_DEBUG_CHECKS
 __device__ unsigned int g_stack_overflows;
