@@ -43,7 +43,7 @@ WORKLOADS = {
     "CornellBox": dict(scene="CornellBox", width=1920, height=1080, spp=1024, batch=64, label="BASELINE.json configs[1]"),
     "glossy_planes": dict(scene="glossy_planes", width=1920, height=1080, spp=256, batch=64, label="BASELINE.json configs[2]"),
     "Test_textured": dict(scene="Test", textures=True, width=3840, height=2160, spp=64, batch=16, label="BASELINE.json configs[3]"),
-    "heightfield": dict(scene="heightfield", width=3840, height=2160, spp=4096, batch=32, label="BASELINE.json configs[4]"),
+    "heightfield": dict(scene="heightfield", width=3840, height=2160, spp=4096, batch=64, label="BASELINE.json configs[4]"),
 }
 
 
