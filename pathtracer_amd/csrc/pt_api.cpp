@@ -162,7 +162,7 @@ struct pt_scene {
     std::vector<pt_bvh_node4> nodes4;  // deep trees: the four-wide device tree
     uint32_t stack_need = 0;           // entries the deepest path of the device tree needs
     DevBuf d_nodes4;
-    DevBuf d_nodes, d_tris, d_uvs, d_leaf_of, d_mats, d_texs, d_lights, d_emissive, d_prims, d_tri_shade, d_tri_basis, d_eye_nodes, d_eye_tris, d_ctr;
+    DevBuf d_nodes, d_tris, d_uvs, d_leaf_of, d_mats, d_texs, d_lights, d_emissive, d_prims, d_tri_shade, d_tri_basis, d_eye_nodes, d_eye_tris, d_tri_edges, d_ctr;
     std::vector<DevBuf*> d_texels;
     Workspace ws;
     std::mutex mu;
@@ -751,6 +751,12 @@ static int scene_create_impl(const pt_scene_desc* d, int device_id, const pt_sce
     dv.n_mats = d->n_mats;
     dv.lds_scene = dv.eye_nodes && dv.n_nodes <= (uint32_t)ptd::kLdsScene && d->n_tris <= (uint32_t)ptd::kLdsScene &&
                    d->n_mats <= (uint32_t)ptd::kLdsMats && d->n_prims == 0 && opt(o.lds_scene, true);
+    dv.tri_edges = nullptr;
+    if (dv.lds_scene) {
+        HIP_TRY(s->d_tri_edges.alloc((size_t)d->n_tris * sizeof(ptd::EyeTri)));
+        ptd::launch_build_tri_edges(dv, s->d_tri_edges.as<ptd::EyeTri>(), nullptr);
+        dv.tri_edges = s->d_tri_edges.as<ptd::EyeTri>();
+    }
     HIP_TRY(hipDeviceSynchronize());
     for (int a = 0; a < 3; ++a) dv.background[a] = d->background[a];
 

@@ -122,6 +122,8 @@ struct Scene {
     const TriBasis* tri_basis;  // [n_tris], leaf order, or nullptr (large scenes)
     const EyeNode* eye_nodes;   // primary-ray tables (nullptr: not built for this scene)
     const EyeTri* eye_tris;
+    const EyeTri* tri_edges;    // the same records for the origin (0, 0, 0): e0, e1, e0 x e1 and vo = v0 of every triangle, for
+                                // rays from anywhere (scenes that live in LDS: a ds_read instead of 24 f64 operations per test)
     const uint32_t* leaf_of;  // global triangle id -> leaf-order index
     const Material* mats;
     const Texture* texs;
@@ -324,6 +326,7 @@ void launch_accumulate(const Frame& fr, Sample3 lsample, const unsigned long lon
                        Counters* ctr /* nullptr: no statistics */, hipStream_t st);
 // parity entry points
 void launch_build_eye_tables(const Scene& sc, EyeNode* nodes, EyeTri* tris, hipStream_t st);
+void launch_build_tri_edges(const Scene& sc, EyeTri* tris, hipStream_t st);
 void launch_build_tri_shade(const Scene& sc, TriShade* out, TriBasis* basis /* or nullptr */, hipStream_t st);
 void launch_build_emitters(const Scene& sc, const uint32_t* leaf, uint32_t n, EmitTri* out, hipStream_t st);
 void launch_leaf_to_global(const Scene& sc, uint32_t* tri, uint32_t n, hipStream_t st);

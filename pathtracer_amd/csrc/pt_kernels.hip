@@ -269,6 +269,10 @@ void launch_build_eye_tables(const Scene& sc, EyeNode* nodes, EyeTri* tris, hipS
     if (!n) return;
     hipLaunchKernelGGL(k_build_eye_tables, dim3(blocks_for(n)), dim3(kBlock), 0, st, sc, nodes, tris);
 }
+void launch_build_tri_edges(const Scene& sc, EyeTri* tris, hipStream_t st) {
+    if (!sc.n_tris) return;
+    hipLaunchKernelGGL(k_build_tri_edges, dim3((sc.n_tris + 255) / 256), dim3(256), 0, st, sc, tris);
+}
 void launch_build_emitters(const Scene& sc, const uint32_t* leaf, uint32_t n, EmitTri* out, hipStream_t st) {
     if (!n) return;
     hipLaunchKernelGGL(k_build_emitters, dim3(blocks_for(n)), dim3(kBlock), 0, st, sc, leaf, n, out);

@@ -918,6 +918,8 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value)) void k_path(Scene g
     __shared__ double s_mats[LDS ? kLdsMats * kMatWords : 1];
     __shared__ float4 s_eye_nodes[(LDS && FIRST) ? kLdsScene * 4 : 1];
     __shared__ float4 s_eye_tris[(LDS && FIRST) ? kLdsScene * 7 : 1];
+    constexpr bool kEdges = LDS && (!FIRST || NEE);  // some ray of this kernel is traced by traverse()
+    __shared__ float4 s_edges[kEdges ? kLdsScene * 7 : 1];
     static_assert(sizeof(TriShade) == 32 && sizeof(TriBasis) == 48 && sizeof(EyeNode) == 64 && sizeof(EyeTri) == 112 && sizeof(Material) % 8 == 0, "LDS copies");
     Scene sc = gsc;
     if (LDS) {  // pointers first (compile-time: the address space is then known at every use), data below
@@ -930,6 +932,7 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value)) void k_path(Scene g
             sc.eye_nodes = reinterpret_cast<const EyeNode*>(s_eye_nodes);
             sc.eye_tris = reinterpret_cast<const EyeTri*>(s_eye_tris);
         }
+        if (kEdges) sc.tri_edges = reinterpret_cast<const EyeTri*>(s_edges);
     }
     bool scene_copied = false;
     if (ctr && blockIdx.x == 0 && threadIdx.x == 0)
@@ -966,6 +969,10 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value)) void k_path(Scene g
                 for (uint32_t k = threadIdx.x; k < gsc.n_tris * 3; k += kPathBlock) s_basis[k] = g_basis[k];
             }
             for (uint32_t k = threadIdx.x; k < gsc.n_mats * kMatWords; k += kPathBlock) s_mats[k] = g_mats[k];
+            if (kEdges) {
+                const float4* g_ed = reinterpret_cast<const float4*>(gsc.tri_edges);
+                for (uint32_t k = threadIdx.x; k < gsc.n_tris * 7; k += kPathBlock) s_edges[k] = g_ed[k];
+            }
             if (FIRST) {
                 const float4* g_en = reinterpret_cast<const float4*>(gsc.eye_nodes);
                 const float4* g_et = reinterpret_cast<const float4*>(gsc.eye_tris);
@@ -1000,7 +1007,7 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value)) void k_path(Scene g
             uint32_t leaf = PT_MISS;
             if (on_screen)
                 leaf = (FIRST && (LDS || sc.eye_nodes)) ? traverse_eye<DEPTH, kPathBlock>(sc, d, 1e-5, t, stack + threadIdx.x)
-                                               : traverse<DEPTH, false, false, kPathBlock>(sc, o, d, 1e-5, t, stack + threadIdx.x, nn, nt);
+                                               : traverse<DEPTH, false, false, kPathBlock, LDS>(sc, o, d, 1e-5, t, stack + threadIdx.x, nn, nt);
             shade_vertex<FIRST, LAST, NEE, MATS, true>(sc, fr, bounce, in, i, rec, leaf, t, o, d, ls, r);
             if (NEE && !LAST && sc.fuse_shadow && r.shadow) {
                 // the light sample's visibility, in place: the shadow ray never leaves the registers
@@ -1008,7 +1015,7 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value)) void k_path(Scene g
                 // of additions as the shadow kernel's: the vertex's emission first, then its light sample.
                 double st_max = r.s_tmax;
                 uint32_t nn2 = 0, nt2 = 0;
-                if (traverse<DEPTH, true, false, kPathBlock>(sc, r.n_o, r.s_d, 1e-5, st_max, stack + threadIdx.x, nn2, nt2) == PT_MISS) {
+                if (traverse<DEPTH, true, false, kPathBlock, LDS>(sc, r.n_o, r.s_d, 1e-5, st_max, stack + threadIdx.x, nn2, nt2) == PT_MISS) {
                     if (FIRST) {
                         double* c = ls.c + (size_t)r.slot * 3;
                         if (r.lit) { c[0] += r.s_c.x; c[1] += r.s_c.y; c[2] += r.s_c.z; }

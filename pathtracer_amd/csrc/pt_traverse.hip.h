@@ -92,10 +92,12 @@ struct RayF {
     float chx, chy, chz;  // fl(oh * i), oh = fl(o - E): subtracted from hi * i
     float ix, iy, iz;     // i = fl(1 / d), magnitude capped at 2^100
 };
-// The plane distances are formed as fma(plane, i, -c), c = fl(origin * i): one instruction per plane.
-// Against the sub-then-mul form analysed above the error terms change from 3 u |lo - ol| / |d| to
-// (2 u |lo - ol| + u |ol|) / |d| (rounding of i and of the fma, and of c), still below the
-// (8 u M + 6.9 u |o|) / |d| of slack.  An infinite i would give inf - inf, so |i| is capped at 2^100: on an
+// The plane distances are formed as fma(plane, i, -c), c = fl(origin * i): one instruction per plane, and
+// i itself in f32: i = rcp32(fl32(d)) = (1 / d)(1 + e), |e| <= 3 u (the conversion, and v_rcp_f32's 1 ulp =
+// 2 u).  The factor (1 + e) multiplies both terms alike, so the computed distance is
+// ((lo - ol) / d)(1 + e) + u |ol i| (rounding of c) + u |result| (the fma): against the sub-then-mul form
+// analysed above the error terms change from 3 u |lo - ol| / |d| to (4 u |lo - ol| + u |ol|) / |d|
+// <= (4 u M + 5.0004 u |o|) / |d|, still below the (8 u M + 6.9 u |o|) / |d| of slack.  An infinite i would give inf - inf, so |i| is capped at 2^100: on an
 // axis with |d_k| < 2^-100 the computed slab is then [-s 2^100, +s 2^100] around the box, s >= 2^-21 M
 // its slack, instead of [-inf, inf], which still holds every hit with t <= 2^79 M - all of them unless
 // the whole direction vector is that tiny (|d| < 2^-60: such a ray opens every box, ix = NaN).
@@ -110,7 +112,8 @@ __device__ __forceinline__ RayF make_rayf(D3 o, D3 d) {
     const float olx = (float)(o.x + E), oly = (float)(o.y + E), olz = (float)(o.z + E);
     const float ohx = (float)(o.x - E), ohy = (float)(o.y - E), ohz = (float)(o.z - E);
     RayF r;
-    auto inv = [](double dk) { return copysignf(fminf(fabsf((float)(1. / dk)), 0x1p100f), (float)(1. / dk)); };
+    // i = rcp32(fl32(d_k)): one v_cvt and one v_rcp_f32 (1 ulp) instead of an f64 division (~12 instructions)
+    auto inv = [](double dk) { const float q = __builtin_amdgcn_rcpf((float)dk); return copysignf(fminf(fabsf(q), 0x1p100f), q); };
     r.ix = inv(d.x); r.iy = inv(d.y); r.iz = inv(d.z);
     if (!(fmax(fmax(fabs(d.x), fabs(d.y)), fabs(d.z)) >= 0x1p-60)) r.ix = r.iy = r.iz = __builtin_nanf("");  // no cull
     r.clx = olx * r.ix; r.cly = oly * r.iy; r.clz = olz * r.iz;
@@ -449,7 +452,8 @@ __device__ __forceinline__ void trace_range_vote(const Scene& sc, uint32_t begin
 // a wave are coherent or every ray is short (primary rays: 96 % lane utilisation on CornellBox;
 // scenes under ~500 triangles), and loses by 15-40 % on incoherent rays in deeper trees (measured
 // crossover: DESIGN.md "Traversal scheduling").  Returns leaf-order index / PT_MISS.
-template <int DEPTH, bool ANY, bool STATS, int STRIDE = kTravBlock>
+// EDGES: the triangle test starts from Scene::tri_edges instead of the vertices (the scene-in-LDS kernel).
+template <int DEPTH, bool ANY, bool STATS, int STRIDE = kTravBlock, bool EDGES = false>
 __device__ __forceinline__ uint32_t traverse(const Scene& sc, D3 o, D3 d, double t_min, double& t_max, int* stk,
                                              uint32_t& n_nodes, uint32_t& n_tris) {
     uint32_t best = PT_MISS, best_id = PT_MISS;
@@ -475,13 +479,24 @@ __device__ __forceinline__ uint32_t traverse(const Scene& sc, D3 o, D3 d, double
         int code = ~cur;
         uint32_t first = (uint32_t)code >> 3, cnt = ((uint32_t)code & 7u) + 1u;
         for (uint32_t k = 0; k < cnt; ++k) {
-            const float4* tp = sc.tris + (size_t)(first + k) * 3;
-            float4 a = tp[0], b = tp[1], c = tp[2];
-            TriV tr = widen(a, b, c);
-            if (STATS) n_tris += 1;
             double t, v, w;
-            if (!tri_test(tr, o, d, t_min, t_max, t, v, w)) continue;
-            uint32_t gid = (uint32_t)__float_as_int(a.w);
+            uint32_t gid;
+            if (STATS) n_tris += 1;
+            if (EDGES) {
+                const EyeTri& e = sc.tri_edges[first + k];
+                TriPre p;
+                p.e0 = ld3(e.e0); p.e1 = ld3(e.e1); p.normal = ld3(e.normal);
+                p.vo = ld3(e.vo) - o;             // tri_pre: vo = v0 - o, num = vo . normal
+                p.num = dot(p.vo, p.normal);
+                if (!tri_test_core(p, d, t_min, t_max, t, v, w)) continue;
+                gid = e.gid;
+            } else {
+                const float4* tp = sc.tris + (size_t)(first + k) * 3;
+                float4 a = tp[0], b = tp[1], c = tp[2];
+                TriV tr = widen(a, b, c);
+                if (!tri_test(tr, o, d, t_min, t_max, t, v, w)) continue;
+                gid = (uint32_t)__float_as_int(a.w);
+            }
             // the reference accepts t == t_max (triangle_mesh.rs:113) and keeps the candidate
             // tested last; the build-defined rule keeps the lowest triangle id
             if (best != PT_MISS && !(t < t_max || gid < best_id)) continue;
@@ -499,8 +514,8 @@ __device__ __forceinline__ uint32_t traverse(const Scene& sc, D3 o, D3 d, double
 
 // ---- primary rays of a small scene: the eye-relative tables (pt_device.h EyeNode / EyeTri) -----
 // slab32 with the subtraction done once per scene: r = (lo - o - E, hi - o + E) rounded outward to f32 by
-// k_build_eye_tables (directed, so only the two roundings of fl(r * fl(1/d)) remain: 2 u |r| of error
-// against 8 u M + 8 u |o| of slack)
+// k_build_eye_tables (directed, so only the reciprocal's 3 u and the product's rounding remain: 4 u |r| of
+// error against 8 u M + 8 u |o| of slack)
 __device__ __forceinline__ bool slab_rel(const float* r, float ix, float iy, float iz, float t_min, float t_max, float& t_near) {
     float ax = r[0] * ix, bx = r[3] * ix;
     float ay = r[1] * iy, by = r[4] * iy;
@@ -540,13 +555,29 @@ __global__ void k_build_eye_tables(Scene sc, EyeNode* nodes, EyeTri* tris) {
         e.pad = 0;
     }
 }
+// Scene::tri_edges: the origin-independent part of tri_pre per triangle (the EyeTri of the origin (0, 0, 0):
+// v0 - 0 is v0 exactly), by the same expressions, so a test that starts from the record gives the same bits
+__global__ void k_build_tri_edges(Scene sc, EyeTri* tris) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sc.n_tris) return;
+    TriPre p = tri_pre(load_tri(sc, i), mk(0., 0., 0.));
+    EyeTri& e = tris[i];
+    e.e0[0] = p.e0.x; e.e0[1] = p.e0.y; e.e0[2] = p.e0.z;
+    e.e1[0] = p.e1.x; e.e1[1] = p.e1.y; e.e1[2] = p.e1.z;
+    e.normal[0] = p.normal.x; e.normal[1] = p.normal.y; e.normal[2] = p.normal.z;
+    e.vo[0] = p.vo.x; e.vo[1] = p.vo.y; e.vo[2] = p.vo.z;
+    e.num = p.num;
+    e.gid = (uint32_t)__float_as_int(sc.tris[(size_t)i * 3].w);
+    e.pad = 0;
+}
 // traverse() for a ray that starts at the eye (closest hit only)
 template <int DEPTH, int STRIDE>
 __device__ __forceinline__ uint32_t traverse_eye(const Scene& sc, D3 d, double t_min, double& t_max, int* stk) {
     uint32_t best = PT_MISS, best_id = PT_MISS;
     if (sc.n_prims) prims_closest(sc, ld3(sc.cam.eye), d, t_min, t_max, best, best_id);
     if (sc.n_nodes == 0) return best;
-    const float ix = (float)(1. / d.x), iy = (float)(1. / d.y), iz = (float)(1. / d.z);
+    // (f32 reciprocals of the converted direction: |relative error| <= 3 u, slab_rel's bound becomes 4 u |r|)
+    const float ix = __builtin_amdgcn_rcpf((float)d.x), iy = __builtin_amdgcn_rcpf((float)d.y), iz = __builtin_amdgcn_rcpf((float)d.z);
     const float t_min32 = f32_down(t_min);
     float t_max32 = f32_up(t_max);
     int sp = 0;
