@@ -904,11 +904,14 @@ template <int DEPTH, bool LDS = false> struct PathBlock {
 // ds_read instead of a trip through the vector L1.
 constexpr int kMatWords = (int)(sizeof(Material) / sizeof(double));
 template <int DEPTH, bool FIRST, bool LAST, bool NEE, int MATS, bool LDS = false>
+#ifndef PT_TEX_WAVES
+#define PT_TEX_WAVES 5
+#endif
 // Waves per SIMD asked of the compiler: the texture code (MATS bit 0) lifts the kernels to 106-109 VGPRs, one
 // step above the 96 that let a fifth wave in; bounded to 5 they spill 36-92 B per lane and still gain (textured
 // Test.obj 4K 22.5 -> 24.4 Gsamples/s, with NEE 12.8 -> 13.6).  The untextured kernels fit already; bounding
 // them too measured -0.4 ... -4 % on CornellBox and 0 on glossy_planes.
-__global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), ((MATS & 1) ? 5 : 1)) void k_path(Scene gsc, Frame fr, uint32_t bounce, Queue in, Live live, Queue out,
+__global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), ((MATS & 1) ? PT_TEX_WAVES : 1)) void k_path(Scene gsc, Frame fr, uint32_t bounce, Queue in, Live live, Queue out,
                                                  Push out_push, ShadowQueue sq, Push sq_push, Sample3 ls,
                                                  Counters* ctr) {
     constexpr int kPathBlock = PathBlock<DEPTH, LDS>::value;
