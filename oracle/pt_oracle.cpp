@@ -653,7 +653,7 @@ struct Builder {
     }
 };
 
-inline bool slab(const BNode& n, V3 o, V3 inv, double t_min, double t_max) {
+inline bool slab(const BNode& n, V3 o, V3 inv, double t_min, double t_max, double& t_enter) {
     double t0 = t_min, t1 = t_max;
     const double oo[3] = {o.x, o.y, o.z}, ii[3] = {inv.x, inv.y, inv.z};
     for (int a = 0; a < 3; ++a) {
@@ -665,20 +665,27 @@ inline bool slab(const BNode& n, V3 o, V3 inv, double t_min, double t_max) {
         t0 = std::fmax(t0, std::fmin(ta, tb));
         t1 = std::fmin(t1, std::fmax(ta, tb));
     }
+    t_enter = t0;
     // widen the interval a little: the triangle test's t and the slab's t round differently
     return t0 <= t1 * (1 + 1e-9) + 1e-300;
 }
 
+// Nearer child first, so that the closest hit found so far prunes the rest (the result does not depend on
+// the order: every leaf whose box the ray enters before that hit is tested, and ties go to the lowest id).
 inline Hit closest_bvh(const Scene& sc, V3 o, V3 d, double t_min, double t_max) {
     Hit best = closest_prims(sc, o, d, t_min, t_max);
     if (sc.nodes.empty()) return best;
     V3 inv = v3(1. / d.x, 1. / d.y, 1. / d.z);
-    int stack[128];
+    struct Item { int node; double t_enter; };
+    Item stack[128];
     int sp = 0;
-    stack[sp++] = 0;
+    double te;
+    if (!slab(sc.nodes[0], o, inv, t_min, best.t, te)) return best;
+    stack[sp++] = {0, te};
     while (sp) {
-        const BNode& n = sc.nodes[stack[--sp]];
-        if (!slab(n, o, inv, t_min, best.t)) continue;
+        const Item it = stack[--sp];
+        if (!(it.t_enter <= best.t * (1 + 1e-9) + 1e-300)) continue;  // a closer hit was found since it was pushed
+        const BNode& n = sc.nodes[it.node];
         if (n.left < 0) {
             for (uint32_t i = n.first; i < n.first + n.count; ++i) {
                 uint32_t id = sc.order[i];
@@ -688,8 +695,14 @@ inline Hit closest_bvh(const Scene& sc, V3 o, V3 d, double t_min, double t_max) 
                 best.tri = id; best.t = t; best.v = v; best.w = w;
             }
         } else {
-            stack[sp++] = n.left;
-            stack[sp++] = n.right;
+            double tl = 0., tr = 0.;
+            const bool hl = slab(sc.nodes[n.left], o, inv, t_min, best.t, tl);
+            const bool hr = slab(sc.nodes[n.right], o, inv, t_min, best.t, tr);
+            if (hl && hr) {
+                if (tl <= tr) { stack[sp++] = {n.right, tr}; stack[sp++] = {n.left, tl}; }
+                else { stack[sp++] = {n.left, tl}; stack[sp++] = {n.right, tr}; }
+            } else if (hl) stack[sp++] = {n.left, tl};
+            else if (hr) stack[sp++] = {n.right, tr};
         }
     }
     return best;

@@ -488,6 +488,18 @@ def test_config5_full_size_heightfield_10m(gpu, monkeypatch):
     assert np.array_equal(tri[pick], btri) and np.array_equal(bits(t[pick]), bits(bt))
     whole = scene.render(cfg)
     assert np.isfinite(whole).all() and whole.mean() > 0.01
+    # ... and 24 full rows of the image against the oracle walking its own tree (median split, f64 boxes): every
+    # bounce of every sample of those pixels, the numbers recorded with the other full-size comparisons
+    oracle = O.OracleScene(data)
+    rows = list(range(40, 2160, 90))
+    ref = np.zeros_like(whole)
+    for y in rows:
+        oracle.render(cfg, ref, tile=(0, y, 3840, y + 1), threads=16, use_bvh=True)
+    del oracle
+    a, b = whole[rows], ref[rows]
+    nums = parity_numbers(a, b, 1e-9, cfg.samples_pr_pixel)
+    record_parity("config5_heightfield_10M_3840x2160_2spp", nums)
+    assert b.mean() > 0.01 and nums["fraction_over_tolerance"] < 2e-3, nums
     acc = scene.render(cfg, None, sample_begin=0, sample_count=1)
     scene.render(cfg, acc, sample_begin=1, sample_count=1)
     assert acc.tobytes() == whole.tobytes()
