@@ -48,6 +48,20 @@ static int check_tree(const float* verts, uint32_t nv, const uint32_t* tris, uin
 int main(int argc, char** argv) {
     const std::string models = argc > 1 ? argv[1] : "models";
     const std::string tmp = argc > 2 ? argv[2] : "/tmp";
+#ifdef PT_THREADS_ONLY  // the ThreadSanitizer build: the multi-threaded builder alone (parallel binning, partition, subtrees)
+    {
+        std::mt19937 rng(3);
+        const uint32_t nt = 150000;
+        std::vector<float> v((size_t)nt * 9);
+        std::vector<uint32_t> idx((size_t)nt * 3);
+        std::uniform_real_distribution<float> u(-10.f, 10.f);
+        for (auto& x : v) x = u(rng);
+        for (uint32_t i = 0; i < nt * 3; ++i) idx[i] = i;
+        for (uint32_t threads : {2u, 5u}) if (check_tree(v.data(), nt * 3, idx.data(), nt, 2, threads)) return 1;
+        std::puts("threaded build clean under tsan");
+        return 0;
+    }
+#endif
     // ---- the reference's scenes through the loader, every wiring flag
     for (const char* name : {"CornellBox", "Test", "glossy_planes", "cornell_box"}) {
         for (uint32_t flags : {0u, (uint32_t)(PT_LOAD_GLOSSY | PT_LOAD_TEXTURES | PT_LOAD_SPECULAR), (uint32_t)(PT_LOAD_GLOSSY | PT_LOAD_GGX)}) {
