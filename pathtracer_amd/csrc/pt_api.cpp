@@ -172,7 +172,7 @@ struct pt_scene {
     pt_stats stats{};
     std::vector<TimedLaunch> timed;
     std::vector<hipEvent_t> event_pool;
-    int pipeline = 0;               // 0: one lane; 1: two lanes on two streams (see Lane)
+    int pipeline = 0;               // 0: one lane; 1: two lanes on two streams for small batches (see Lane); 2: always two
     int persistent = 1;             // vote-scheduled launches claim their ranges from work cursors
     int screen_cull = 1;            // primary rays outside the scene's screen bounds are not generated
     hipStream_t side = nullptr;     // the second lane's stream
@@ -253,6 +253,7 @@ int ensure_workspace(pt_scene* s, uint32_t slots, uint32_t lane_slots, int n_lan
 }
 
 constexpr uint64_t kMinLanePaths = 1u << 20;  // below this a lane cannot fill 256 CUs; keep one lane
+constexpr uint64_t kMaxTwoLanePaths = 100000000;  // above this one lane is as fast (see pt_render_device)
 
 int ensure_side_stream(pt_scene* s, size_t n_events) {
     if (!s->side) HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
@@ -703,7 +704,7 @@ static int scene_create_impl(const pt_scene_desc* d, int device_id, const pt_sce
     }
     s->persistent = opt(o.persistent, s->persistent);
     s->screen_cull = opt(o.screen_cull, s->screen_cull);
-    s->pipeline = opt(o.pipeline, dv.bvh_depth > 8);
+    s->pipeline = o.pipeline < 0 ? (dv.bvh_depth > 8 ? 1 : 0) : (o.pipeline ? 2 : 0);  // 2: asked for, at any batch size
     dv.mat_features = 0;
     for (uint32_t i = 0; i < d->n_mats; ++i) {
         if (d->mats[i].tex >= 0) dv.mat_features |= 1u;
@@ -1069,8 +1070,11 @@ int pt_render_device(pt_scene* s, const pt_render_params* P_in, double* accum_de
     if (s->ws_used) HIP_TRY(hipStreamWaitEvent(st, s->ws_free, 0));
     bool two = false;
     for (;;) {
-        // two lanes when a batch has frames to split and enough paths for each half to fill the chip
-        two = s->pipeline != 0 && spp >= 2 && (uint64_t)(spp / 2) * npix >= kMinLanePaths;
+        // two lanes when a batch has frames to split, enough paths for each half to fill the chip, and is small
+        // enough for a launch's tail to matter (10 M-triangle scene at 4K, one lane -> two: batches of 8 / 16 /
+        // 32 / 64 frames +1.9 / +0.9 / -0.5 / -0.3 %; a forced pipeline - options, tests - keeps two at any size)
+        two = s->pipeline != 0 && spp >= 2 && (uint64_t)(spp / 2) * npix >= kMinLanePaths &&
+              (s->pipeline > 1 || (uint64_t)spp * npix < kMaxTwoLanePaths);
         const uint32_t lane_spp = two ? spp - spp / 2 : spp;
         rc = ensure_workspace(s, spp * npix, lane_spp * npix, two ? 2 : 1, nee, diffs);
         if (rc != PT_ERR_NOMEM || spp == 1 || P->spp_per_batch != 0) break;
