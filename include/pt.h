@@ -258,7 +258,9 @@ typedef struct pt_scene_options {
     int8_t persistent;       /* persistent launch of the vote-scheduled traversal kernels */
     int8_t eye_tables;       /* per-scene tables for rays from the eye (shallow trees of <= 65 536 triangles) */
     int8_t lds_scene;        /* a tiny scene lives in LDS inside the fused kernel (needs eye_tables) */
-    int8_t reserved;
+    int8_t group_frames;     /* k = 1..6: a wave of primary rays holds 64 / 2^k pixels of an 8x8 block in 2^k frames
+                              * instead of the whole block in one frame; 0 = off (default: deep trees 6 - one pixel in 64
+                              * frames, as far as the frame count of a batch divides -, others 0) */
     uint32_t wave_rays;      /* rays per vote-scheduled range: a power of two in 64..1024 (default 512) */
     uint32_t bvh_max_leaf;   /* triangles per leaf of the library's own BVH build, 1..8 (default 2) */
     uint32_t bvh_threads;    /* host threads of that build, 1..64 (default: the hardware's, at most 16) */
@@ -267,7 +269,7 @@ typedef struct pt_scene_options {
 void pt_scene_options_init(pt_scene_options* options);
 /* ... then the overrides of the process environment, for tuning sweeps without a rebuild: PT_TRAV_VOTE_PRIMARY,
  * PT_TRAV_VOTE, PT_TRAV_VOTE_SHADOW, PT_FUSE, PT_FUSE_SHADOW, PT_LIGHT_CULL, PT_SCREEN_CULL, PT_PIPELINE,
- * PT_PERSISTENT, PT_EYE_TABLES, PT_LDS_SCENE = 0|1; PT_WAVE_RAYS, PT_BVH_LEAF, PT_BVH_THREADS = counts.  This is the
+ * PT_PERSISTENT, PT_EYE_TABLES, PT_LDS_SCENE = 0|1; PT_GROUP_FRAMES = 0..6; PT_WAVE_RAYS, PT_BVH_LEAF, PT_BVH_THREADS = counts.  This is the
  * only function of the library that reads the environment. */
 void pt_scene_options_from_env(pt_scene_options* options);
 

@@ -175,6 +175,7 @@ struct pt_scene {
     int pipeline = 0;               // 0: one lane; 1: two lanes on two streams for small batches (see Lane); 2: always two
     int persistent = 1;             // vote-scheduled launches claim their ranges from work cursors
     int screen_cull = 1;            // primary rays outside the scene's screen bounds are not generated
+    int group_frames = 0;           // slot order: up to 2^group_frames frames of a few pixels per wave (Frame::grp_log2)
     hipStream_t side = nullptr;     // the second lane's stream
     hipEvent_t ws_free = nullptr;   // recorded at the end of every pt_render_device call: the workspace is free again
     bool ws_used = false;
@@ -409,7 +410,7 @@ void pt_scene_options_init(pt_scene_options* o) {
     memset(o, 0, sizeof *o);
     o->struct_size = (uint32_t)sizeof *o;
     o->vote_primary = o->vote_secondary = o->vote_shadow = o->fuse = o->fuse_shadow = o->light_cull = o->screen_cull =
-        o->pipeline = o->persistent = o->eye_tables = o->lds_scene = PT_OPT_DEFAULT;
+        o->pipeline = o->persistent = o->eye_tables = o->lds_scene = o->group_frames = PT_OPT_DEFAULT;
 }
 
 void pt_scene_options_from_env(pt_scene_options* o) {
@@ -434,6 +435,7 @@ void pt_scene_options_from_env(pt_scene_options* o) {
     flag("PT_PERSISTENT", o->persistent);
     flag("PT_EYE_TABLES", o->eye_tables);
     flag("PT_LDS_SCENE", o->lds_scene);
+    if (const char* e = getenv("PT_GROUP_FRAMES")) if (*e) o->group_frames = (int8_t)std::max(0, std::min(6, atoi(e)));
     count("PT_WAVE_RAYS", o->wave_rays);
     if (!valid_wave_rays(o->wave_rays)) o->wave_rays = 0;  // a sweep's bad value falls back to the default
     count("PT_BVH_LEAF", o->bvh_max_leaf);
@@ -704,6 +706,11 @@ static int scene_create_impl(const pt_scene_desc* d, int device_id, const pt_sce
     }
     s->persistent = opt(o.persistent, s->persistent);
     s->screen_cull = opt(o.screen_cull, s->screen_cull);
+    // (10 M-triangle scene at 4K, batches of 64 frames, 1 / 4 / 8 / 16 / 32 / 64 frames per wave: 10.13 / 10.74 / 11.06 /
+    // 11.31 / 11.59 / 11.79 Gsamples/s.  A tree that lives in LDS gains nothing from coherent primary rays - its
+    // bounce-0 waves are full already - and k_accumulate's radiance reads lose their coalescing: CornellBox -2 %,
+    // glossy_planes -3.4 % at 64; so only deep trees by default.)
+    s->group_frames = o.group_frames < 0 ? (dv.bvh_depth > 8 ? 6 : 0) : std::min<int>(o.group_frames, 6);
     s->pipeline = o.pipeline < 0 ? (dv.bvh_depth > 8 ? 1 : 0) : (o.pipeline ? 2 : 0);  // 2: asked for, at any batch size
     dv.mat_features = 0;
     for (uint32_t i = 0; i < d->n_mats; ++i) {
@@ -908,7 +915,7 @@ int render_batches(pt_scene* s, const pt_render_params* P, double* accum_dev, hi
     struct LaneRun {  // one lane's share of the batch
         Lane* ln;
         hipStream_t st;
-        ptd::Frame fr;
+        ptd::Frame fr{};
         ptd::Sample3 ls;
         uint32_t n_max, seg, cap;
     };
@@ -951,7 +958,7 @@ int render_batches(pt_scene* s, const pt_render_params* P, double* accum_dev, hi
 
     for (uint32_t b0 = 0; b0 < P->sample_count; b0 += spp) {
         const uint32_t ns = std::min(spp, P->sample_count - b0);
-        ptd::Frame fr;
+        ptd::Frame fr{};
         fr.width = P->width; fr.height = P->height;
         fr.x0 = P->x0; fr.y0 = P->y0; fr.tile_w = tw; fr.tile_h = th;
         fr.row_group = fr.row_off = fr.row_skip = 0;
@@ -961,6 +968,7 @@ int render_batches(pt_scene* s, const pt_render_params* P, double* accum_dev, hi
             fr.row_skip = (P->row_parts - 1) * P->row_group;
         }
         fr.n_tile_pixels = npix;
+        fr.grp_log2 = fr.grp1_log2 = 0;
         fr.n_samples = ns;
         fr.sample_base = P->sample_begin + b0;
         fr.seed = P->seed;
@@ -988,6 +996,10 @@ int render_batches(pt_scene* s, const pt_render_params* P, double* accum_dev, hi
             r.fr.jitter = fr.jitter + (size_t)s0 * 2;
             r.ls.c = w.ls.c + (size_t)3 * s0 * npix;
             r.ls.lit = w.lane[l].lit;
+            // deep trees: the lane's frames eight (four, two) at a time, so that a wave of primary rays is a row of
+            // eight pixels in eight frames instead of an 8x8 block in one (Frame::grp_log2)
+            r.fr.grp_log2 = 0;
+            while ((int)r.fr.grp_log2 < s->group_frames && (r.fr.n_samples & ((2u << r.fr.grp_log2) - 1u)) == 0) ++r.fr.grp_log2;
             r.n_max = (s1 - s0) * npix;
             r.seg = ptd::seg_size_for(r.n_max);  // <= the size the lane was carved for
             r.cap = ptd::kSegs * r.seg;
@@ -1020,6 +1032,8 @@ int render_batches(pt_scene* s, const pt_render_params* P, double* accum_dev, hi
             HIP_TRY(hipEventRecord(ev[1], sd));  // join
             HIP_TRY(hipStreamWaitEvent(st, ev[1], 0));
         }
+        fr.grp_log2 = run[0].fr.grp_log2;
+        fr.grp1_log2 = n_run == 2 ? run[1].fr.grp_log2 : 0;
         {
             Timer t(s, st, PT_K_ACCUMULATE);
             ptd::launch_accumulate(fr, w.ls, n_run == 2 ? w.lane[1].lit : nullptr, run[0].fr.n_samples, accum_dev,

@@ -257,6 +257,14 @@ struct Frame {  // per-call constants of generate / shade
     uint32_t n_on_screen;            // pixels of the tile inside those bounds (the primary rays actually traced, per frame)
     uint32_t w8, h8, n8, bw, rw;     // tile_w & ~7, tile_h & ~7, w8 * h8, w8 / 8, tile_w - w8 (0 -> 1 for the divisor)
     FastDiv div_bw, div_rw;
+    // Slot order across the frames of a lane: G = 1 << grp_log2 frames at a time (G divides the lane's frame
+    // count).  G = 1: frame after frame (slot = s * pixels + slot in frame).  G > 1: inside a group of G frames
+    // a wave's 64 slots are 64 / G pixels of one 8x8 block - whole rows of it - in each of the G frames, so a
+    // wave of primary rays covers G x fewer pixels and its rays differ by the frame jitter alone (pt_math.hip.h
+    // slot_sp / sp_slot); the pixels outside whole blocks follow, frame after frame.  grp1_log2: the second
+    // lane's, for k_accumulate, which reads both.
+    uint32_t grp_log2, grp1_log2;
+    FastDiv div_rest;                // / (n_tile_pixels - n8)
     // Interleaved row partition (pt_render_params::row_group / row_parts / row_index): tile_h counts only
     // the rows this call renders, and tile row ty is image row y0 + row_off + ty + (ty / row_group) *
     // row_skip, row_off = row_index * row_group, row_skip = (row_parts - 1) * row_group.  All zero = every
@@ -275,6 +283,7 @@ inline void finish_frame(Frame& fr) {  // (cx0..cy1 are set by the caller; defau
     fr.rw = fr.tile_w - fr.w8;
     fr.div_bw = make_fastdiv(fr.bw ? fr.bw : 1u);
     fr.div_rw = make_fastdiv(fr.rw ? fr.rw : 1u);
+    fr.div_rest = make_fastdiv(fr.n_tile_pixels > fr.n8 ? fr.n_tile_pixels - fr.n8 : 1u);
     fr.div_group = make_fastdiv(fr.row_group ? fr.row_group : 1u);
     auto overlap = [](uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1) {
         uint32_t lo = a0 > b0 ? a0 : b0, hi = a1 < b1 ? a1 : b1;

@@ -103,6 +103,39 @@ __device__ __forceinline__ void slot_pixel(const Frame& fr, uint32_t p, uint32_t
         ty = fr.h8 + yy;
     }
 }
+// Slot of a lane <-> (frame of the lane s, slot in the frame p): Frame::grp_log2 = lg, G = 1 << lg <= 64.
+// Inside a group of G frames wave (block b, part j) holds, for each of the G frames, the 64 / G pixels
+// [j * 64 / G, (j + 1) * 64 / G) of the 8x8 block b in its row-major order: lane = f * (64 / G) + q.
+__device__ __forceinline__ void slot_sp(const Frame& fr, uint32_t lg, uint32_t slot, uint32_t& s, uint32_t& p) {
+    const uint32_t frame = fdiv(slot, fr.div_pixels);
+    if (lg == 0) { s = frame; p = slot - frame * fr.n_tile_pixels; return; }
+    const uint32_t g = frame >> lg;                              // floor(floor(slot / pixels) / G)
+    const uint32_t r = slot - (g << lg) * fr.n_tile_pixels;      // within the group of G frames
+    const uint32_t n8g = fr.n8 << lg;
+    if (r < n8g) {
+        const uint32_t l = r & 63u, wj = r >> 6;                 // lane of the wave; wave = block * G + j
+        const uint32_t b = wj >> lg, j = wj & ((1u << lg) - 1u);
+        const uint32_t f = l >> (6u - lg), q = l & ((64u >> lg) - 1u);
+        s = (g << lg) + f;
+        p = (b << 6) + (j << (6u - lg)) + q;
+    } else {
+        const uint32_t rr = r - n8g, rest = fr.n_tile_pixels - fr.n8;
+        const uint32_t f = fdiv(rr, fr.div_rest);
+        s = (g << lg) + f;
+        p = fr.n8 + (rr - f * rest);
+    }
+}
+__device__ __forceinline__ size_t sp_slot(const Frame& fr, uint32_t lg, uint32_t s, uint32_t p) {
+    if (lg == 0) return (size_t)s * fr.n_tile_pixels + p;
+    const uint32_t g = s >> lg, f = s & ((1u << lg) - 1u);
+    const size_t base = (size_t)(g << lg) * fr.n_tile_pixels;
+    if (p < fr.n8) {
+        const uint32_t b = p >> 6, w = p & 63u;
+        const uint32_t j = w >> (6u - lg), q = w & ((64u >> lg) - 1u);
+        return base + ((((size_t)b << lg) + j) << 6) + (f << (6u - lg)) + q;
+    }
+    return base + ((size_t)fr.n8 << lg) + (size_t)f * (fr.n_tile_pixels - fr.n8) + (p - fr.n8);
+}
 __device__ __forceinline__ PixelArgs pixel_args(uint32_t px, uint32_t py, uint32_t w, uint32_t h, double dx, double dy,
                                                 double aspect /* (double)w / (double)h: 1.0 for the reference's square images (F7) */) {
     double pixel_size_x = 1. / (double)w, pixel_size_y = 1. / (double)h;

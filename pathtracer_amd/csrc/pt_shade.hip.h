@@ -585,7 +585,8 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
     constexpr bool TEX = (MATS & 1) != 0, SPEC = (MATS & 2) != 0;
     const uint32_t slot = rec.slot;
     r.slot = slot;
-    uint32_t s = fdiv(slot, fr.div_pixels), p = slot - s * fr.n_tile_pixels;
+    uint32_t s, p;
+    slot_sp(fr, fr.grp_log2, slot, s, p);
     uint32_t ty, tx;
     slot_pixel(fr, p, tx, ty);
     const uint32_t gy_ = frame_row(fr, ty);
@@ -994,7 +995,8 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), ((MATS & 1) ? PT_TE
             D3 o = mk(0., 0., 0.), d = o;
             bool on_screen = true;  // FIRST: the pixel lies inside the scene's screen bounds (Frame::cx0..)
             if (FIRST) {
-                uint32_t s = fdiv(i, fr.div_pixels), p = i - s * fr.n_tile_pixels;
+                uint32_t s, p;
+                slot_sp(fr, fr.grp_log2, i, s, p);
                 uint32_t ty, tx;
                 slot_pixel(fr, p, tx, ty);
                 const uint32_t gx = fr.x0 + tx, gy = frame_row(fr, ty);
@@ -1067,11 +1069,13 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(Frame fr, Sample3 ls, con
     constexpr uint32_t kGroup = 8;
     for (uint32_t s0 = 0; s0 < fr.n_samples; s0 += kGroup) {
         unsigned long long word[kGroup];
+        size_t slot_of[kGroup];
 #pragma unroll
         for (uint32_t j = 0; j < kGroup; ++j) {
             const uint32_t s = min(s0 + j, fr.n_samples - 1u);
-            const size_t k = (size_t)s * fr.n_tile_pixels + slot_in_frame;
-            const size_t kl = s < split ? k : k - (size_t)split * fr.n_tile_pixels;  // slot within its lane
+            // slot within its lane (each lane orders its own frames: Frame::grp_log2)
+            const size_t kl = s < split ? sp_slot(fr, fr.grp_log2, s, slot_in_frame) : sp_slot(fr, fr.grp1_log2, s - split, slot_in_frame);
+            slot_of[j] = s < split ? kl : (size_t)split * fr.n_tile_pixels + kl;  // ... and within the batch's radiance array
             word[j] = (s < split ? ls.lit : lit1)[kl >> 6] >> (kl & 63u);
         }
 #pragma unroll
@@ -1080,7 +1084,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(Frame fr, Sample3 ls, con
             if (s >= fr.n_samples) break;
             double cr = 0., cg = 0., cb = 0.;  // a sample without a value is +0 (Sample3)
             if (word[j] & 1ull) {
-                const double* c = ls.c + ((size_t)s * fr.n_tile_pixels + slot_in_frame) * 3;
+                const double* c = ls.c + slot_of[j] * 3;
                 cr = c[0]; cg = c[1]; cb = c[2];
                 ++n_lit;
             }

@@ -714,7 +714,8 @@ __global__ __launch_bounds__(kTravBlock, PT_TRAV_WAVES) void k_extend(Scene sc, 
     uint32_t nn = 0, nt = 0;
     auto fetch = [&](uint32_t i, D3& o, D3& d, double& t_min, double& t_max) {
             if (PRIMARY) {
-                uint32_t s = fdiv(i, fr.div_pixels), p = i - s * fr.n_tile_pixels;
+                uint32_t s, p;
+                slot_sp(fr, fr.grp_log2, i, s, p);
                 uint32_t ty, tx;
                 slot_pixel(fr, p, tx, ty);
                 const uint32_t gx = fr.x0 + tx, gy = frame_row(fr, ty);

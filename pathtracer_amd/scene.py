@@ -246,7 +246,7 @@ class Scene:
             o = L.pt_scene_options()
             L.lib.pt_scene_options_init(C.byref(o))
             for k, v in options.items():
-                if k not in dict(o._fields_) or k in ("struct_size", "reserved"):
+                if k not in dict(o._fields_) or k == "struct_size":
                     raise ValueError(f"unknown scene option {k!r}")
                 setattr(o, k, int(v))
             L.check(L.lib.pt_scene_create_ex(C.byref(d), device, C.byref(o), C.byref(self._h)))

@@ -296,6 +296,31 @@ def test_scene_options_select_the_same_variants_as_the_environment(gpu, monkeypa
     assert differ >= 2                                       # unfused and vote-scheduled paths launch other kernels
 
 
+@pytest.mark.parametrize("name", ["CornellBox", "heightfield40"])
+def test_frame_grouping_is_bitwise_invariant(gpu, name):
+    # pt_scene_options::group_frames: which slot a (frame, pixel) pair takes - a wave of primary rays holds one
+    # pixel in 64 frames, or 64 / G pixels in G frames, instead of an 8x8 block in one frame - is invisible in the
+    # image: frame counts that divide by 64, by smaller powers of two and by none, tiles with pixels outside whole
+    # 8x8 blocks, sample ranges, two lanes, a row partition, NEE.
+    from pathtracer_amd.synthetic import heightfield_box
+    data = heightfield_box(cells=40) if name == "heightfield40" else pt.scene_data(name)
+    plain = pt.Scene(data, gpu, options=dict(group_frames=0))
+    for k, extra in ((6, {}), (3, {}), (6, dict(pipeline=1)), (1, dict(fuse=0))):
+        grouped = pt.Scene(data, gpu, options=dict(group_frames=k, **extra))
+        for kw, spp, tile, rows in ((dict(width=211, height=97), 64, None, None),
+                                    (dict(width=83, height=47, nee=True), 24, None, None),
+                                    (dict(width=200, height=120), 7, None, None),
+                                    (dict(width=200, height=120), 48, (13, 9, 171, 100), None),
+                                    (dict(width=96, height=200), 16, None, (8, 3, 1))):
+            cfg = pt.Config(samples_pr_pixel=spp, bounces=2, seed=9, drop_nonfinite=True, **kw)
+            a = plain.render(cfg, tile=tile, rows=rows)
+            b = grouped.render(cfg, tile=tile, rows=rows)
+            assert a.any() and a.tobytes() == b.tobytes(), (k, extra, kw, spp)
+            c = grouped.render(cfg, None, sample_begin=0, sample_count=spp // 2, tile=tile, rows=rows)
+            grouped.render(cfg, c, sample_begin=spp // 2, sample_count=spp - spp // 2, tile=tile, rows=rows)
+            assert c.tobytes() == a.tobytes()
+
+
 @pytest.mark.parametrize("wave_rays", ["64", "128", "1024"])
 def test_schedulers_agree_bitwise(gpu, monkeypatch, wave_rays):
     from pathtracer_amd.synthetic import heightfield_box

@@ -44,9 +44,9 @@ def test_struct_layouts_match_the_header():
 def test_scene_options_defaults_environment_and_validation(monkeypatch):
     o = L.pt_scene_options()
     L.lib.pt_scene_options_init(C.byref(o))
-    flags = [n for n, t in L.pt_scene_options._fields_ if t is C.c_int8 and n != "reserved"]
+    flags = [n for n, t in L.pt_scene_options._fields_ if t is C.c_int8]
     assert o.struct_size == 28 and all(getattr(o, n) == -1 for n in flags)
-    assert (o.wave_rays, o.bvh_max_leaf, o.bvh_threads, o.reserved) == (0, 0, 0, 0)
+    assert (o.wave_rays, o.bvh_max_leaf, o.bvh_threads) == (0, 0, 0)
     # the environment is read by pt_scene_options_from_env alone (the sweeps' hook, what pt_scene_create uses)
     for k, v in (("PT_FUSE", "0"), ("PT_TRAV_VOTE", "1"), ("PT_WAVE_RAYS", "128"), ("PT_BVH_LEAF", "4"), ("PT_LDS_SCENE", "0")):
         monkeypatch.setenv(k, v)
