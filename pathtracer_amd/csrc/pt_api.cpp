@@ -709,14 +709,15 @@ static int scene_create_impl(const pt_scene_desc* d, int device_id, const pt_sce
     // (10 M-triangle scene at 4K, batches of 64 frames, 1 / 4 / 8 / 16 / 32 / 64 frames per wave: 10.13 / 10.74 / 11.06 /
     // 11.31 / 11.59 / 11.79 Gsamples/s.  A tree that lives in LDS gains nothing from coherent primary rays - its
     // bounce-0 waves are full already - and k_accumulate's radiance reads lose their coalescing: CornellBox -2 %,
-    // glossy_planes -3.4 % at 64; so only deep trees by default.)
-    s->group_frames = o.group_frames < 0 ? (dv.bvh_depth > 8 ? 6 : 0) : std::min<int>(o.group_frames, 6);
+    // glossy_planes -3.4 % at 64; so only deep trees by default - set below, once the materials are known.)
     s->pipeline = o.pipeline < 0 ? (dv.bvh_depth > 8 ? 1 : 0) : (o.pipeline ? 2 : 0);  // 2: asked for, at any batch size
     dv.mat_features = 0;
     for (uint32_t i = 0; i < d->n_mats; ++i) {
         if (d->mats[i].tex >= 0) dv.mat_features |= 1u;
         if (d->mats[i].kind != PT_MAT_LAMBERT) dv.mat_features |= 2u;
     }
+    // ... a textured scene gains too (its waves then look one texel up: Test.obj 4K +3 %)
+    s->group_frames = o.group_frames < 0 ? ((dv.bvh_depth > 8 || (dv.mat_features & 1u)) ? 6 : 0) : std::min<int>(o.group_frames, 6);
     dv.light_area = acc;
     dv.n_area_lights = d->n_area_lights;
     for (int a = 0; a < 7; ++a) dv.area_light[a] = 0.;
