@@ -1075,7 +1075,12 @@ int pt_render_device(pt_scene* s, const pt_render_params* P_in, double* accum_de
     // queues out of 288; 16 / 32 / 64 frames at 4K -> 9.17 / 9.43 / 9.65 Gsamples/s on that scene), halved
     // while the allocation does not fit.
     uint32_t spp = P->spp_per_batch;
-    if (spp == 0) spp = std::max<uint32_t>(1u, (1u << 28) / npix);
+    if (spp == 0) {
+        spp = std::max<uint32_t>(1u, (1u << 28) / npix);
+        // whole groups of frames (Frame::grp_log2): a multiple of 64, or the power of two below
+        if (spp >= 64u) spp &= ~63u;
+        else while (spp & (spp - 1u)) spp &= spp - 1u;
+    }
     spp = std::min(spp, P->sample_count);
     spp = std::min<uint32_t>(spp, std::max<uint32_t>(1u, (1u << 30) / npix));
     // All renders of a scene share its workspace (queues, hit records, counters, per-sample radiance,
