@@ -53,7 +53,14 @@ __global__ void k_sample_brdf(Scene sc, Frame fr, uint32_t bounce, const double*
     int lobe;
     if (m.kind == PT_MAT_MIRROR || m.kind == PT_MAT_TRANSPARENT) bs = {mk(1., 1., 1.), specular_sample(m, d, normal, xi1, lobe), -1.};  // pdf < 0: specular
     else if (is_glossy(m.kind)) bs = glossy_sample(m.width, ld3(m.color), d, normal, xi1, xi2, m.kind == PT_MAT_GLOSSY_GGX);
-    else bs = lambertian_sample(diffuse, normal, xi1, xi2);
+    else {
+        // the code the renders run (shade_vertex): the direction from lambertian_dir over the triangle's stored
+        // basis; f = rho / pi and pdf = (n . wi) / pi as material.rs:37-58 (the render's throughput factor is the
+        // closed form rho; the test checks f |wi . n| / pdf against it)
+        const TriBasis* basis = (sc.tri_basis && leaf < PT_PRIM_BASE) ? sc.tri_basis + leaf : nullptr;
+        const D3 w = lambertian_dir(normal, basis, xi1, xi2);
+        bs = {diffuse * PT_FRAC_1_PI, w, dot(normal, w) * PT_FRAC_1_PI};
+    }
     D3 le = m.kind != PT_MAT_LAMBERT ? mk(0., 0., 0.) : ld3(m.emission);
     f[3 * i] = bs.f.x; f[3 * i + 1] = bs.f.y; f[3 * i + 2] = bs.f.z;
     wi[3 * i] = bs.wi.x; wi[3 * i + 1] = bs.wi.y; wi[3 * i + 2] = bs.wi.z;

@@ -368,17 +368,8 @@ __device__ RayDiffs spawn_diffs(const Material& m, int lobe, D3 position, D3 sur
     }
     return nr;
 }
-// material.rs:9-23 + 37-58
-__device__ __forceinline__ Brdf lambertian_sample(D3 color, D3 n, double xi1, double xi2) {
-    double cos_theta = sqrt(xi1);
-    double sin_theta = sqrt(1.0 - xi1);
-    double phi = 2.0 * PT_PI * xi2;
-    double sp, cp;
-    sincos(phi, &sp, &cp);
-    D3 wi = rotate_to(mk(sin_theta * cp, sin_theta * sp, cos_theta), n);
-    return {color * PT_FRAC_1_PI, wi, dot(n, wi) * PT_FRAC_1_PI};
-}
-// The direction alone (material.rs:9-23), with the basis of the normal given (TriBasis) or built here.
+// material.rs:9-23: the cosine-weighted direction, with the basis of the normal given (TriBasis) or built here.
+// (f = rho / pi and pdf = (n . wi) / pi of material.rs:37-58 are one multiplication each, written at their uses.)
 __device__ __forceinline__ D3 lambertian_dir(D3 n, const TriBasis* basis, double xi1, double xi2) {
     double cos_theta = sqrt(xi1);
     double sin_theta = sqrt(1.0 - xi1);

@@ -64,3 +64,39 @@ def heightfield_box(cells: int = 2236, seed: int = 12345, amplitude: float = 40.
                               np.zeros(htris.shape[0], np.uint32)])
     return SceneData(verts, tris, tri_mat, mats, camera=CAMERAS["Test"], background=(0.0, 0.0, 0.0),
                      model_names=["box", "heightfield"], model_first_tri=[0, int(keep.sum())])
+
+
+def tilted_mirror(normal=(0.17846472, 0.96215658, -0.2059249), roughness: float = 0.0) -> SceneData:
+    """A 2 x 2 Glossy quad (Beckmann width max(roughness, 1e-5), microfacet.rs:125) with a normal that is
+    NOT axis-aligned, under a large emissive quad, seen from along its normal.
+
+    Why it exists: the reference accumulates NaN samples (main.rs:434-436) when `Beckmann::D` takes the
+    acos of a dot product that rounds past 1 (microfacet.rs:161-173).  That needs a half vector within
+    ~1e-8 rad of a normal whose components are not 0 / +-1: on glossy_planes.obj every plane is
+    axis-aligned, h.n is then a single component of a normalised vector and can never exceed 1 (67 M oracle
+    samples: no non-finite value), so the mode only shows on a tilted surface like this one.  With the
+    default normal the oracle yields 11 NaN pixels at 256 x 256 x 64 spp, seed 1 (tests pin that)."""
+    from .scene import Camera
+    from . import _lib as L
+
+    n = np.array(normal, np.float64)
+    n /= np.linalg.norm(n)
+    a = np.cross(n, [0.0, 0.0, 1.0])
+    a /= np.linalg.norm(a)
+    b = np.cross(n, a)
+    quad = [-a - b, a - b, a + b, -a + b]
+    s = 30.0
+    sky = [(-s, 6.0, -s), (s, 6.0, -s), (s, 6.0, s), (-s, 6.0, s)]
+    verts = np.array(quad + sky, np.float32)
+    tris = np.array([[0, 1, 2], [0, 2, 3], [4, 5, 6], [4, 6, 7]], np.uint32)
+    mats = np.zeros(2, dtype=MATERIAL_DTYPE)
+    mats["tex"] = -1
+    mats["color"][0] = 0.9
+    mats["roughness"][0] = roughness
+    mats["kind"][0] = L.PT_MAT_GLOSSY
+    mats["kind"][1] = L.PT_MAT_LAMBERT
+    mats["emission"][1] = 1.0
+    eye = n * 3.0 + a * 0.4
+    view = -eye / np.linalg.norm(eye)
+    cam = Camera(tuple(eye), tuple(view), (0.0, 1.0, 0.0), 2.0)
+    return SceneData(verts, tris, [0, 0, 1, 1], mats, camera=cam, model_names=["mirror", "sky"], model_first_tri=[0, 2])

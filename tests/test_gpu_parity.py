@@ -719,6 +719,32 @@ def test_lds_scene_boundary_sizes(gpu, monkeypatch, n_tris):
     assert np.array_equal(tri, rtri) and np.array_equal(bits(t), bits(rt))
 
 
+def test_config1_as_named_full_image(scenes):
+    # BASELINE.json configs[0] as named: CornellBox 512 x 512, 16 frames x 1 spp, bounces 2 (the reference's own
+    # CPU-runnable case: --dim 512, main.rs:346-347 defaults).  The WHOLE image, HIP path vs oracle (4.2 M samples),
+    # frame by frame through the frame loop's shape (one frame per call, main.rs:400-436) and in one call.
+    data, scene, oracle = scenes["CornellBox"]
+    spp = 16
+    cfg = pt.Config(dim=512, samples_pr_pixel=spp, bounces=2, seed=1)
+    img = scene.render(cfg)
+    ref = oracle.render(cfg, threads=16, use_bvh=True)
+    nums = parity_numbers(img, ref, 1e-9, spp)
+    record_parity("config1_CornellBox_512x512_16spp_full_image", nums)
+    assert ref.mean() > 0.05 * spp / 16 and np.isfinite(img).all()
+    assert nums["rel_rmse"] <= 1e-9, nums
+    assert nums["fraction_over_tolerance"] < 1e-3, nums
+    assert nums["identical_8bit"], nums
+    loop = np.zeros_like(img)
+    for frame in range(spp):                                  # pixels[i] += next[i], one frame per call
+        scene.render(cfg, loop, sample_begin=frame, sample_count=1)
+    assert loop.tobytes() == img.tobytes()
+    # primary hits of the whole 512 x 512 frame 0: ids and distances bit-exact
+    rays = oracle.generate_rays(cfg, 0)
+    tri, t = scene.trace_closest(rays)
+    rtri, rt = oracle.trace_closest(rays, use_bvh=False)
+    assert np.array_equal(tri, rtri) and np.array_equal(bits(t), bits(rt))
+
+
 def test_config2_converged_image_psnr(scenes):
     # BASELINE.json configs[1] as named: CornellBox 1920x1080 at 1024 spp.  The converged image under
     # identical per-pixel RNG streams against the oracle on a strided set of full rows: relative RMSE
@@ -769,13 +795,13 @@ def test_config3_converged_glossy_psnr(gpu):
 
 
 def test_config3_glossy_full_size_nonfinite_samples_as_the_reference(gpu):
-    # BASELINE.json configs[2] at its full size in the reference's own mode: non-finite samples (a Beckmann
-    # strip of width 1e-5 takes acos of a dot product that rounds past 1) are ACCUMULATED, as main.rs:434-436
-    # does, not dropped.  A pixel is then NaN on both sides or on neither, except where that rounding falls
-    # differently in ocml and glibc: stated bound, at most 1 pixel value in 10 000 differs in finiteness; the
-    # pixels finite on both sides agree as in the drop_nonfinite comparison (99.5 % within 1e-6).
-    # (Measured, profiles/r02/parity.json: at this size, seed and depth the whole device image holds no
-    # non-finite value at all, so the two modes coincide here; the small-size NaN-mask test is test_gpu_shading's.)
+    # BASELINE.json configs[2] at its full size in the reference's own mode: non-finite samples are ACCUMULATED, as
+    # main.rs:434-436 does, not dropped.  On THIS scene there are none, and there cannot be: Beckmann::D's acos
+    # (microfacet.rs:161-173) is NaN only when h.n rounds past 1, and every plane of glossy_planes.obj is
+    # axis-aligned, so h.n is one component of a normalised vector (<= 1 exactly; 67 M oracle samples and the
+    # whole 1080p device image hold no non-finite value).  The test therefore pins that the two modes coincide at
+    # full size; the NaN-accumulating mode itself is tested where NaNs are known to exist:
+    # test_gpu_shading.test_nan_accumulating_mode_on_a_tilted_near_mirror.
     data = pt.scene_data("glossy_planes", glossy=True)
     scene, oracle = pt.Scene(data, gpu), O.OracleScene(data)
     spp = 32
@@ -793,5 +819,5 @@ def test_config3_glossy_full_size_nonfinite_samples_as_the_reference(gpu):
     nums["rows_compared"] = len(rows)
     nums["nonfinite_values_in_whole_gpu_image"] = int((~np.isfinite(img)).sum())
     record_parity("config3_glossy_planes_1920x1080_32spp_nonfinite_accumulated", nums)
-    assert nums["nonfinite_mask_mismatch"] <= 1e-4 * a.size, nums
+    assert nums["nonfinite_values_in_whole_gpu_image"] == 0 and nums["nonfinite_oracle"] == 0, nums
     assert nums["fraction_over_tolerance"] < 5e-3, nums

@@ -250,3 +250,40 @@ def test_nee_converges_to_the_same_image():
     bn = naive.reshape(4, 4, 4, 4, 3).mean(axis=(1, 3))
     be = nee.reshape(4, 4, 4, 4, 3).mean(axis=(1, 3))
     assert np.abs(be - bn).max() < 0.15 * bn.max()
+
+
+def test_config1_as_named_on_the_oracle():
+    # BASELINE.json configs[0] as named — CornellBox 512 x 512, 16 frames x 1 spp, bounces 2, the reference's own
+    # CPU-runnable case — on the oracle: the whole image (4.2 M samples).  The frame loop's shape (one frame per
+    # call, main.rs:400-436) equals one call bitwise; brute force and the oracle's own BVH agree bitwise on a band;
+    # the mean radiance is pinned (a libm change would move it in the 12th digit at most).
+    o = O.OracleScene(pt.scene_data("CornellBox"))
+    cfg = pt.Config(dim=512, samples_pr_pixel=16, bounces=2, seed=1)
+    img = o.render(cfg, threads=8, use_bvh=True)
+    assert np.isfinite(img).all()
+    assert abs(img.mean() - 13.956334696459352) <= 1e-9 * 13.956334696459352
+    assert img.max() <= 16 * 36.8 + 1e-9                      # 16 direct views of the light (CornellBox.mtl Ka 36.8 31.2 16.0)
+    loop = np.zeros_like(img)
+    for frame in range(16):
+        o.render(cfg, loop, sample_begin=frame, sample_count=1, threads=8, use_bvh=True)
+    assert loop.tobytes() == img.tobytes()
+    band = np.zeros_like(img)
+    o.render(cfg, band, tile=(0, 250, 512, 262), threads=8, use_bvh=False)
+    assert band[250:262].tobytes() == img[250:262].tobytes()
+
+
+def test_oracle_nan_accumulating_mode_is_pinned():
+    # main.rs:434-436 accumulates whatever render() returns; microfacet.rs:161-173 returns NaN once h.n rounds
+    # past 1.  Found with the oracle alone (scripts: DESIGN.md section 2 "NaN mode"): the tilted alpha = 1e-5 quad
+    # of synthetic.tilted_mirror yields NaN pixels at 256 x 256 x 64 spp, seed 1, while glossy_planes.obj
+    # (axis-aligned planes) cannot.  The GPU test compares the HIP path on exactly this input.
+    from pathtracer_amd.synthetic import tilted_mirror
+    o = O.OracleScene(tilted_mirror())
+    img = o.render(pt.Config(dim=256, samples_pr_pixel=64, seed=1, bounces=2))
+    bad = ~np.isfinite(img).all(axis=2)
+    assert bad.sum() >= 5, bad.sum()                          # 11 with glibc 2.35
+    assert np.isnan(img[bad]).all() and not np.isinf(img).any()    # NaN poisons all three channels of a pixel
+    clean = o.render(pt.Config(dim=256, samples_pr_pixel=64, seed=1, bounces=2, drop_nonfinite=True))
+    assert np.isfinite(clean).all() and clean[~bad].tobytes() == img[~bad].tobytes()
+    g = O.OracleScene(pt.scene_data("glossy_planes"))
+    assert np.isfinite(g.render(pt.Config(dim=128, samples_pr_pixel=32, seed=1))).all()
