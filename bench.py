@@ -10,16 +10,21 @@ frames.  The scene and the accumulation buffer are resident in HBM before the ti
 
 With N > 1 and no launcher in the environment, bench.py starts its own N ranks (a child
 `python -m torch.distributed.run`, before this process touches the GPU).  The work is cut by
-pathtracer_amd/dist.py: `--partition samples` (default) gives every rank the whole image for its own
-1024 frames per step (fixed per-GPU work => weak scaling) and hands the partial sums to rank 0, added
-in rank order, once, at the end of the timed region; `--partition tiles` gives every rank the row groups
-g % N == rank of the one image (fixed total work => strong scaling) and gathers the rows to rank 0.
+pathtracer_amd/dist.py.  Default `--partition tiles`: the ONE image of the N = 1 workload, every rank the
+row groups g % N == rank of it (fixed total work => "scaling": "strong"; `samples_per_step` equals the
+1-GPU line's), and the rows are gathered to rank 0 INSIDE every step - an image is done when rank 0 holds
+it - with the exchange's share reported as `exchange_ms_per_step`.  After the headline run the same ranks
+time `--partition samples` (every rank the whole image for its own 1024 frames per step, partial sums added
+on rank 0 in rank order once per step: fixed per-GPU work, weak scaling) and both appear under "partitions".
 
 At N = 1 the other BASELINE configs (glossy_planes 1080p, textured Test.obj 4K, the 10 M-triangle
 heightfield 4K) are timed for a few steps each after the headline and reported under "configs", each
 with its own roofline; `--configs none` skips them.
 
 Prints ONE JSON line on rank 0; see DESIGN.md "Measurement" for the roofline / cpu_baseline fields.
+`value` counts every sample of the frame; `value_on_screen` only those whose primary ray was generated (the
+scene's screen bounds skip the others), `value_no_culls` is a short run of the same workload with both exact
+culls off (every ray the reference's render() would trace is traced).
 """
 import argparse
 import json
@@ -68,18 +73,32 @@ def load_pmc():
         return {}
 
 
+def pmc_is_stale(entry):
+    """The counters of profiles/pmc.json belong to the kernel sources they were collected on (their git blob
+    hashes, scripts/pmc_digest.py): stale when the working tree's differ, or when none were recorded."""
+    from pathtracer_amd.buildinfo import kernel_source_hashes
+    return entry.get("_sources") != kernel_source_hashes()
+
+
 class Workload:
     """One scene + config on this rank's GPU, with the step / instrumentation / roofline logic."""
 
-    def __init__(self, pt, torch, wl, args, dev, local_rank, part=None):
+    def __init__(self, pt, torch, wl, args, dev, local_rank, part=None, data=None, options=None):
         self.pt, self.torch, self.wl, self.args, self.dev, self.part = pt, torch, wl, args, dev, part
-        if wl["scene"] == "heightfield":
+        if data is not None:
+            self.data = data
+        elif wl["scene"] == "heightfield":
             from pathtracer_amd.synthetic import heightfield_box
             self.data = heightfield_box(args.cells)
         else:
             self.data = pt.scene_data(wl["scene"], textures=bool(wl.get("textures")))
-        self.scene = pt.Scene(self.data, device=local_rank)
+        self.scene = pt.Scene(self.data, device=local_rank, options=options)
         self.w, self.h, self.spp, self.batch = wl["width"], wl["height"], wl["spp"], wl["batch"]
+        if part is not None and part.mode != "samples":
+            # a rank renders 1 / world of the image: world x the frames per pass keep the paths in flight (and the
+            # workspace) what they are at N = 1; the image is bitwise independent of the batch size (tested)
+            self.batch = min(self.spp, self.batch * part.world)
+        self.exchange_events = []
         self.cfg = pt.Config(width=self.w, height=self.h, bounces=args.bounces, seed=1, spp_per_batch=self.batch, nee=args.nee)
         self.accum = torch.zeros((self.h, self.w, 3), dtype=torch.float64, device=dev)
         self.stream = torch.cuda.current_stream(dev).cuda_stream
@@ -90,13 +109,28 @@ class Workload:
         self.scene.render_device(self.cfg, accum.data_ptr(), s0, n, tile=tile, stream=self.stream, rows=rows)
 
     def step(self, i):
-        """Step i: frames [i * spp * world', +spp * world') of the job, this rank's share of them."""
+        """Step i.  One GPU: the next spp frames are added to the running sums.  N > 1: one complete image per
+        step - the ranks render their shares into zeroed sums and hand them to rank 0 (Partition.exchange), inside
+        the step; HIP events on the launch stream bracket the exchange."""
         if self.part is None:
             self.render_fn(self.accum, None, i * self.spp, self.spp, None)
-        elif self.part.mode == "samples":   # the job's step = world x spp frames, spp of them here
+            return
+        self.accum.zero_()
+        if self.part.mode == "samples":   # the job's step = world x spp frames, spp of them here
             self.part.render(self.render_fn, self.accum, i * self.spp * self.world, self.spp * self.world)
-        else:                                # every rank the same spp frames, its own rows
+        else:                             # every rank the same spp frames, its own rows
             self.part.render(self.render_fn, self.accum, i * self.spp, self.spp)
+        a, b = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+        a.record()
+        self.part.exchange(self.accum)
+        b.record()
+        self.exchange_events.append((a, b))
+
+    def exchange_ms(self):
+        """Sum over the recorded steps (call after a synchronize), and forget them."""
+        ms = sum(a.elapsed_time(b) for a, b in self.exchange_events)
+        self.exchange_events = []
+        return ms
 
     def pixels(self):
         return self.part.pixels() if (self.part is not None and self.part.mode != "samples") else self.w * self.h
@@ -181,7 +215,9 @@ class Workload:
         # rocprofv3 PMC passes of this same workload, committed under profiles/ (scripts/pmc_collect.sh ->
         # scripts/pmc_digest.py -> profiles/pmc.json): per launch of each kernel kind, HBM traffic
         # ((FETCH_SIZE x 2 on gfx950) + WRITE_SIZE), VALU busy cycles, VALU instructions, lane cycles
-        pmc = load_pmc().get(pmc_key(self.wl, args.bounces, args.nee), {}).get(dom, {})
+        pmc_entry = load_pmc().get(pmc_key(self.wl, args.bounces, args.nee), {})
+        pmc = pmc_entry.get(dom, {})
+        pmc_stale = pmc_is_stale(pmc_entry) if pmc else None
         hbm = {
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc.get("traffic_bytes_per_launch"),
@@ -218,12 +254,18 @@ class Workload:
                 "valu_insts_per_launch": pmc.get("valu_insts_per_launch"),
                 "fp64_tflops": round(flops / (avg_ms * 1e-3) / 1e12, 2) if flops else None,
                 "fp64_peak_tflops_no_fma": FP64_VALU_PEAK_TFLOPS / 2,
+                # how much of the issue rate is f64 arithmetic on live lanes (the rest: f32 box tests, integer RNG and
+                # address work, selects, moves, idle lanes): the useful-work fraction beside the issue-slot fraction
+                "fp64_frac": round(flops / (avg_ms * 1e-3) / 1e12 / (FP64_VALU_PEAK_TFLOPS / 2), 4) if flops else None,
                 "waves_per_simd": pmc.get("waves_per_simd"),
             }
         # the bound: a scene that lives in cache / LDS is bound by vector issue, the 10 M-triangle scene by HBM gathers
         main = dict(valu if (resident and valu) else hbm)
         main.update({
             "kernel": dom, "avg_launch_ms": round(avg_ms, 4), "launches": launches,
+            # counter-derived figures (traffic, VALU cycles, lane utilisation, flops) come from profiles/pmc.json:
+            # true = a kernel source has changed since they were collected (durations are always live)
+            "pmc_stale": pmc_stale,
             "hbm": hbm if (resident and valu) else None, "valu": valu if not resident else None,
             "pmc": {k: pmc.get(k) for k in ("valu_busy", "lane_utilisation", "waves_per_simd", "l2_hit", "clock_ghz")} if pmc else None,
             "scene_cache_resident": resident, "scene_bytes": scene_bytes, "tree_width": st["tree_width"], "stack_need": st["stack_need"],
@@ -244,13 +286,19 @@ class Workload:
     def describe(self):
         wl, args = self.wl, self.args
         name = wl["scene"] + ("" if wl["scene"] == "heightfield" else ".obj")
+        if self.part is None:
+            share = f"{self.spp} spp per step"
+        elif self.part.mode == "samples":
+            share = f"{self.spp} spp per step per GPU ({self.spp * self.world} per step)"
+        else:
+            share = f"{self.spp} spp per step, the image's rows shared by {self.world} GPUs"
         return (f"{name} {self.w}x{self.h} bounces={args.bounces}{', NEE' if args.nee else ''}"
-                f"{', textures' if wl.get('textures') else ''}, {self.spp} spp per step per GPU in batches of {self.batch}"
-                f" ({wl['label']})")
+                f"{', textures' if wl.get('textures') else ''}, {share}, in batches of {self.batch} ({wl['label']})")
 
 
-def timed_run(torch, dist, wk, steps, warmup, world, backend, exchange=None):
-    """W untimed + K timed steps bracketed by barrier + synchronize; returns (seconds [max over ranks], stats)."""
+def timed_run(torch, dist, wk, steps, warmup, world, backend):
+    """W untimed + K timed steps bracketed by barrier + synchronize; returns (seconds [max over ranks], stats,
+    exchange ms of this rank over the K steps)."""
     dev = wk.dev
 
     def fence():
@@ -262,23 +310,23 @@ def timed_run(torch, dist, wk, steps, warmup, world, backend, exchange=None):
     for i in range(warmup):
         wk.step(i)
     fence()
+    wk.exchange_ms()
     wk.scene.reset_stats()
     wk.scene.set_profiling(1)  # HIP events around every kernel launch of the timed region, on the launch stream
     fence()
     t0 = time.perf_counter()
     for i in range(steps):
         wk.step(warmup + i)
-    if exchange is not None:
-        exchange()
     fence()
     dt = time.perf_counter() - t0
+    ex_ms = wk.exchange_ms()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     st = wk.scene.stats()
     wk.scene.set_profiling(0)
-    return dt, st
+    return dt, st, ex_ms
 
 
 def main():
@@ -293,10 +341,15 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--cells", type=int, default=2236, help="heightfield resolution (2236 -> 9,999,392 triangles)")
     ap.add_argument("--bounces", type=int, default=2)
-    ap.add_argument("--partition", choices=("samples", "tiles", "bands"), default="samples",
-                    help="N > 1: 'samples' = every rank the whole image for its own frames, partial sums added on "
-                         "rank 0 in rank order (weak scaling, the measured default); 'tiles' = interleaved groups of 8 "
-                         "rows of the one image, one gather (SURVEY.md §8e.1, strong scaling); 'bands' = contiguous bands")
+    ap.add_argument("--partition", choices=("tiles", "bands", "samples"), default="tiles",
+                    help="N > 1, the headline run: 'tiles' = interleaved groups of 8 rows of the ONE image of the N = 1 "
+                         "workload, gathered to rank 0 every step (SURVEY.md §8e.1; fixed total work, strong scaling); "
+                         "'bands' = contiguous bands; 'samples' = every rank the whole image for its own frames, partial "
+                         "sums added on rank 0 in rank order every step (fixed per-GPU work, weak scaling)")
+    ap.add_argument("--other-partition", choices=("auto", "none"), default="auto",
+                    help="N > 1: after the headline run, time the other of tiles / samples too (under \"partitions\")")
+    ap.add_argument("--no-cull-steps", type=int, default=3,
+                    help="N = 1: steps of the run with both exact culls off behind `value_no_culls` (0 = skip)")
     ap.add_argument("--nee", action="store_true", help="next-event estimation (shadow rays) on")
     ap.add_argument("--configs", choices=("all", "none"), default="all",
                     help="N = 1: also time the other BASELINE configs for a few steps each")
@@ -341,22 +394,41 @@ def main():
         if getattr(args, k):
             wl[k] = getattr(args, k)
     wl["batch"] = min(wl["batch"], wl["spp"])
-    part = Partition(args.partition, wl["width"], wl["height"]) if world > 1 else None
-    wk = Workload(pt, torch, wl, args, dev, local_rank, part)
-
-    if world > 1 and backend == "nccl":
-        # first use of a collective builds channels and loads its kernels: not part of a step
-        part.exchange(torch.zeros_like(wk.accum))
-    dt, st = timed_run(torch, dist, wk, args.steps, args.warmup, world, backend,
-                       exchange=(lambda: part.exchange(wk.accum)) if world > 1 else None)
-
-    samples_per_rank = wk.pixels() * wk.spp * args.steps
     tdev = dev if backend == "nccl" else "cpu"
-    tot = torch.tensor([float(st["rays"]), float(samples_per_rank)], dtype=torch.float64, device=tdev)
-    if world > 1:
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    total_rays, total_samples = float(tot[0].item()), float(tot[1].item())
-    value = total_samples / dt / 1e6
+    PARTITIONING = {"samples": "sample ranges: every rank the whole image for its own frames, partial sums gathered and "
+                               "added in rank order on rank 0, every step",
+                    "tiles": "interleaved groups of 8 rows of the one image, gathered to rank 0 every step",
+                    "bands": "contiguous row bands of the one image, gathered to rank 0 every step"}
+
+    def measure(mode, data=None):
+        """The K timed steps under partition `mode` (None: one GPU).  Returns the workload and what it achieved."""
+        part = Partition(mode, wl["width"], wl["height"]) if world > 1 else None
+        wk = Workload(pt, torch, wl, args, dev, local_rank, part, data=data)
+        if world > 1 and backend == "nccl":
+            # first use of a collective builds channels and loads its kernels: not part of a step
+            part.exchange(torch.zeros_like(wk.accum))
+        dt, st, ex_ms = timed_run(torch, dist, wk, args.steps, args.warmup, world, backend)
+        samples_per_rank = wk.pixels() * wk.spp * args.steps
+        tot = torch.tensor([float(st["rays"]), float(samples_per_rank)], dtype=torch.float64, device=tdev)
+        ex = torch.tensor([ex_ms], dtype=torch.float64, device=tdev)
+        if world > 1:
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            dist.all_reduce(ex, op=dist.ReduceOp.MAX)   # rank 0 waits for every sender: its share is the exchange's
+        res = {"dt": dt, "st": st, "samples_per_rank": samples_per_rank, "total_rays": float(tot[0].item()),
+               "total_samples": float(tot[1].item()), "exchange_ms_per_step": float(ex.item()) / args.steps}
+        res["value"] = res["total_samples"] / dt / 1e6
+        return wk, res
+
+    def summary(mode, r):
+        return {"value": round(r["value"], 3), "unit": "Msamples/s", "scaling": "weak" if mode == "samples" else "strong",
+                "ms_per_step": round(r["dt"] / args.steps * 1e3, 3),
+                "exchange_ms_per_step": round(r["exchange_ms_per_step"], 4),
+                "samples_per_step": int(r["total_samples"] / args.steps), "partitioning": PARTITIONING[mode]}
+
+    mode = args.partition if world > 1 else None
+    wk, res = measure(mode)
+    dt, st, value = res["dt"], res["st"], res["value"]
+    samples_per_rank, total_rays, total_samples = res["samples_per_rank"], res["total_rays"], res["total_samples"]
 
     out = None
     if rank == 0:
@@ -383,29 +455,52 @@ def main():
                    "sample": f"{n_frames} frames (spp) of the same {wk.w}x{wk.h} {wl['scene']} workload, "
                              f"{cdt:.1f} s; C++ f64 restatement of the Rust loop (rustc absent, SURVEY F1)"}
             del oracle, acc
-        tiles = world > 1 and args.partition != "samples"
-        partitioning = "single GPU"
-        if world > 1:
-            partitioning = {"samples": "sample ranges, partial sums gathered and added in rank order on rank 0",
-                            "tiles": "interleaved groups of 8 rows, one gather to rank 0",
-                            "bands": "contiguous row bands, one gather to rank 0"}[args.partition]
         out = {
             "metric": "Msamples/s", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "strong" if tiles else "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": "weak" if mode == "samples" else "strong",
+            "vs_baseline": None, "dtype": "f64",
             "data": (f"synthetic heightfield box, {wk.data.n_tris} triangles, seed 12345" if wl["scene"] == "heightfield"
                      else f"reference scene models/{wl['scene']}.obj") + ", counter-based RNG (no dataset)",
             "config": {"workload": wk.describe(), "triangles": wk.data.n_tris,
                        "exact_culls": {k: os.environ.get(k, "1") != "0" for k in ("PT_SCREEN_CULL", "PT_LIGHT_CULL")},
-                       "partitioning": partitioning,
+                       "partitioning": PARTITIONING[mode] if mode else "single GPU",
                        "samples_per_step": int(total_samples / args.steps)},
             "mrays_per_s": round(total_rays / dt / 1e6, 3),
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+        if world > 1:
+            out["exchange_ms_per_step"] = round(res["exchange_ms_per_step"], 4)
+            out["partitions"] = {mode: summary(mode, res)}
+        if roofline and roofline.get("primary_rays_traced") is not None:
+            # the samples whose primary ray was generated (the others lie outside the scene's screen bounds: their
+            # value is exactly +0 and they cost nothing)
+            out["value_on_screen"] = round(value * roofline["primary_rays_traced"], 3)
         if cpu:
             out["gpu_over_cpu"] = round(value / cpu["value"], 1) if cpu["value"] else None
+    data = wk.data
     del wk
+
+    # ---- N > 1: the other partitioning on the same ranks (tiles <-> samples) ------------------------------
+    if world > 1 and args.other_partition == "auto":
+        other = "samples" if mode != "samples" else "tiles"
+        owk, ores = measure(other, data=data)
+        del owk
+        if rank == 0:
+            out["partitions"][other] = summary(other, ores)
+
+    # ---- N = 1: the same workload with both exact culls off (every ray of the reference's render() is traced) --
+    if rank == 0 and world == 1 and args.no_cull_steps > 0:
+        nwk = Workload(pt, torch, wl, args, dev, local_rank, None, data=data, options={"light_cull": 0, "screen_cull": 0})
+        ndt, nst, _ = timed_run(torch, dist, nwk, args.no_cull_steps, 1, 1, backend)
+        n = nwk.pixels() * nwk.spp * args.no_cull_steps
+        out["value_no_culls"] = round(n / ndt / 1e6, 3)
+        out["no_culls"] = {"steps": args.no_cull_steps, "warmup": 1, "ms_per_step": round(ndt / args.no_cull_steps * 1e3, 3),
+                           "mrays_per_s": round(nst["rays"] / ndt / 1e6, 3),
+                           "rays_per_sample": round(nst["rays"] / max(1, n), 4)}
+        del nwk
+    del data
 
     # ---- the other BASELINE configs, a few steps each (single GPU only) ----------------------------------
     if rank == 0 and world == 1 and args.configs == "all":
@@ -414,7 +509,7 @@ def main():
             if name == args.workload:
                 continue
             owk = Workload(pt, torch, dict(owl), args, dev, local_rank, None)
-            odt, ost = timed_run(torch, dist, owk, args.config_steps, 1, 1, backend)
+            odt, ost, _ = timed_run(torch, dist, owk, args.config_steps, 1, 1, backend)
             n = owk.pixels() * owk.spp * args.config_steps
             others[name] = {
                 "workload": owk.describe(), "triangles": owk.data.n_tris,

@@ -209,7 +209,7 @@ typedef struct pt_render_params {
      * idle while the floor's works).  row_group = 8 keeps the kernels' 8x8-pixel ray blocks whole.
      * row_parts = 0 or 1: every row (the other two fields are ignored). */
     uint32_t row_group, row_parts, row_index;
-    uint32_t reserved;        /* 0 */
+    uint32_t reserved;        /* must be 0 (PT_ERR_INVALID otherwise: zero-initialise the struct) */
 } pt_render_params;
 
 typedef struct pt_kernel_stat {
@@ -279,7 +279,8 @@ void pt_scene_options_from_env(pt_scene_options* options);
 int pt_scene_create_ex(const pt_scene_desc* desc, int device_id, const pt_scene_options* options, pt_scene** out);
 int pt_scene_create(const pt_scene_desc* desc, int device_id, pt_scene** out);
 void pt_scene_destroy(pt_scene* scene);
-/* introspection (host copies owned by the scene, valid until destroy) */
+/* introspection (host copies owned by the scene, valid until destroy).  The boxes are the ones the kernels
+ * test: a caller-supplied tree comes back with its boxes widened by the margin of the f32 slab test. */
 int pt_scene_get_bvh(const pt_scene* scene, const pt_bvh_node** nodes, uint32_t* n_nodes,
                      const uint32_t** tri_order, uint32_t* max_depth);
 
@@ -294,8 +295,10 @@ int pt_bvh_build(const float* verts, uint32_t n_verts, const uint32_t* tris, uin
 /* ---- bvh.rs:17-21 when the host keeps its own builder (north_star: "BVH build in bvh.rs"): checks
  * everything the traversal kernels assume of a caller-supplied tree before pt_scene_create takes it
  * (child indices in range, each inner node reached once, leaf runs inside [0, n_tris) and covering
- * every triangle exactly once, tri_order a permutation, depth within the kernels' 32-entry LDS
- * stack — a deeper tree is PT_ERR_UNSUPPORTED, never silently truncated).  Host only, no device. */
+ * every triangle exactly once, tri_order a permutation, depth <= 32 levels: a shallow tree (depth <= 8) is
+ * walked as given with an 8-entry LDS stack, a deeper one through its four-wide collapse, whose stack need
+ * the collapse bounds by 16 LDS entries + 48 private ones — a tree deeper than 32 levels is
+ * PT_ERR_UNSUPPORTED, never silently truncated).  Host only, no device. */
 int pt_bvh_validate(const pt_bvh_node* nodes, uint32_t n_nodes, const uint32_t* tri_order, uint32_t n_tris,
                     uint32_t* max_depth_out);
 
@@ -362,9 +365,12 @@ int pt_accum_device(pt_accum* acc, double** sums_dev, void** stream);
  * frame of the tile does not fit: 655 360 tile pixels per call (e.g. 1920 x 340), 393 216 with
  * PT_FLAG_NEE, 327 680 with PT_FLAG_PROPAGATE_DIFFS on a textured scene (262 144 with both).  No kernel timing on this
  * path (pt_set_profiling level 1 is ignored; the counters of level 2 work).  Every call on a GPU
- * shares that GPU's array: calls that overlap on one GPU - from two streams, two scenes or two host
- * threads - race; order them on one stream, or with events.  The first call on a device looks the
- * array's address up (no allocation, but make it outside graph capture). */
+ * shares that GPU's array.  Calls from two streams, two scenes or two host threads are ORDERED by the
+ * library (a per-device mutex around the enqueueing and a per-device event that every call's stream
+ * waits for and re-records), so they run one after the other instead of racing; only a stream under
+ * graph capture is left out of that ordering (it cannot wait for an outside event): the caller orders
+ * captured calls.  The first call on a device looks the array's address up and creates that event (no
+ * device memory is allocated, but make it outside graph capture). */
 #define PT_NOALLOC_SCRATCH_BYTES (128u << 20)
 int pt_render_device_noalloc(pt_scene* scene, const pt_render_params* params, double* accum_rgb_dev,
                              void* stream);

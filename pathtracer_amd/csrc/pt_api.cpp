@@ -312,13 +312,14 @@ int collect_timers(pt_scene* s) {
 uint32_t owned_rows(const pt_render_params* p) {
     const uint32_t th = p->y1 - p->y0;
     if (p->row_parts <= 1) return th;
-    const uint32_t G = p->row_group, N = p->row_parts, r = p->row_index;
-    const uint32_t groups = (th + G - 1) / G;           // the last one may be short
+    // (check_params keeps row_group <= height; 64-bit all the same, so that no product can wrap)
+    const uint64_t G = p->row_group, N = p->row_parts, r = p->row_index;
+    const uint64_t groups = (th + G - 1) / G;           // the last one may be short
     if (r >= groups) return 0;
-    const uint32_t mine = (groups - r + N - 1) / N;     // groups r, r + N, ...
-    uint32_t rows = mine * G;
+    const uint64_t mine = (groups - r + N - 1) / N;     // groups r, r + N, ...
+    uint64_t rows = mine * G;
     if ((groups - 1) % N == r) rows -= groups * G - th;  // the short last group is this call's
-    return rows;
+    return (uint32_t)rows;
 }
 
 int check_params(const pt_render_params* p) {
@@ -333,8 +334,12 @@ int check_params(const pt_render_params* p) {
     }
     if (p->max_bounces > kMaxBounces) { set_error("max_bounces > %u", kMaxBounces); return PT_ERR_UNSUPPORTED; }
     if ((uint64_t)(p->x1 - p->x0) * (p->y1 - p->y0) > (1ull << 30)) { set_error("tile too large"); return PT_ERR_UNSUPPORTED; }
-    if (p->row_parts > 1 && (p->row_group == 0 || p->row_index >= p->row_parts)) {
-        set_error("bad row partition: group %u, part %u of %u", p->row_group, p->row_index, p->row_parts);
+    if (p->row_parts > 1 && (p->row_group == 0 || p->row_group > p->height || p->row_index >= p->row_parts)) {
+        set_error("bad row partition: group %u (1..height), part %u of %u", p->row_group, p->row_index, p->row_parts);
+        return PT_ERR_INVALID;
+    }
+    if (p->reserved != 0) {
+        set_error("pt_render_params::reserved is %u, must be 0 (zero-initialise the struct)", p->reserved);
         return PT_ERR_INVALID;
     }
     if ((p->flags & PT_FLAG_REFERENCE_LIGHTS) && (p->flags & PT_FLAG_NEE)) {
@@ -530,7 +535,12 @@ static int scene_create_impl(const pt_scene_desc* d, int device_id, const pt_sce
         if (!d->bvh_tri_order && d->n_tris) { set_error("bvh_nodes given without bvh_tri_order"); return PT_ERR_INVALID; }
         s->nodes.assign(d->bvh_nodes, d->bvh_nodes + d->n_bvh_nodes);
         s->order.assign(d->bvh_tri_order, d->bvh_tri_order + d->n_tris);
-        pth::bvh_widen(s->nodes, d->verts, d->n_verts);  // the margin the f32 box tests need (pt_bvh.cpp)
+        // the caller's tree is checked as given, then widened by the margin the f32 box tests need
+        // (pt_bvh.cpp; pt_scene_get_bvh hands back the widened boxes).  Nothing to widen without triangles.
+        uint32_t depth = 0;
+        int rc = pt_bvh_validate(s->nodes.data(), (uint32_t)s->nodes.size(), s->order.data(), d->n_tris, &depth);
+        if (rc != PT_OK) return rc;
+        if (d->n_tris && d->verts) pth::bvh_widen(s->nodes, d->verts, d->n_verts);
     } else {
         // leaves of at most 2 triangles (a quad): measured against 1/3/4/8 on both bench scenes
         // (CornellBox 13.3/13.6/11.6/11.5, 10 M triangles 3.03/3.42/3.16/2.84 Gsamples/s; 2: 13.6/3.43)
@@ -1063,8 +1073,7 @@ int pt_render_device(pt_scene* s, const pt_render_params* P_in, double* accum_de
     const pt_render_params* P = &clipped;
     const uint32_t tw = P->x1 - P->x0, th = owned_rows(P);  // the rows this call renders
     const uint32_t npix = tw * th;
-    s->stats.samples += n_asked;
-    if (npix == 0) return PT_OK;  // nothing of the tile on screen, or a row partition with more parts than row groups
+    if (npix == 0) { s->stats.samples += n_asked; return PT_OK; }  // nothing of the tile on screen, or a row partition with more parts than row groups
     const bool nee = ptd::samples_lights(s->dev, P->flags);
     // differentials only feed texture filtering: without a texture (or a second vertex) nothing reads them
     const bool diffs = (P->flags & PT_FLAG_PROPAGATE_DIFFS) && (P->flags & PT_FLAG_USE_DIFFS) && s->n_texs > 0 &&
@@ -1110,6 +1119,7 @@ int pt_render_device(pt_scene* s, const pt_render_params* P_in, double* accum_de
     }
     rc = render_batches(s, P, accum_dev, st, w, w.jitter.as<double>(), spp, two, nee, diffs);
     if (rc != PT_OK) return rc;
+    s->stats.samples += n_asked;  // counted once the frames are enqueued, not when a workspace could not be had
     HIP_TRY(hipEventRecord(s->ws_free, st));
     s->ws_used = true;
     if (s->timed.size() >= kMaxPendingTimers) return collect_timers(s);
@@ -1132,6 +1142,13 @@ constexpr int kMaxDevices = 64;
 constexpr uint32_t kNoAllocJitterFrames = 1024;  // frames per batch of a no-alloc call at most (16 KiB of jitters)
 std::mutex g_scratch_mu;
 unsigned char* g_scratch_ptr[kMaxDevices];  // device address of `scratch` on device d (nullptr: not looked up yet)
+// Every call on a GPU shares that GPU's array, whatever scene or stream it comes from.  Per device: a mutex
+// held while a call enqueues its work, and an event recorded behind that work which the next call's stream
+// waits for - so calls from two scenes, two streams or two host threads are ordered on the device instead of
+// overwriting each other's queues.  Made with the symbol lookup (the first call on a device, outside capture).
+std::mutex g_scratch_call_mu[kMaxDevices];
+hipEvent_t g_scratch_done[kMaxDevices];     // recorded at the end of the last call on device d
+bool g_scratch_used[kMaxDevices];
 
 // device `dev` must be current
 int scratch_address(int dev, unsigned char** out) {
@@ -1144,6 +1161,13 @@ int scratch_address(int dev, unsigned char** out) {
             set_error("hipGetSymbolAddress(scratch) on device %d failed: %s", dev, hipGetErrorString(e));
             return PT_ERR_DEVICE;
         }
+        hipEvent_t ev = nullptr;
+        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            set_error("hipEventCreate for the static workspace of device %d failed: %s", dev, hipGetErrorString(e));
+            return PT_ERR_DEVICE;
+        }
+        g_scratch_done[dev] = ev;
         g_scratch_ptr[dev] = (unsigned char*)p;
     }
     *out = g_scratch_ptr[dev];
@@ -1197,6 +1221,13 @@ int pt_render_device_noalloc(pt_scene* s, const pt_render_params* P_in, double* 
     Workspace w;  // pointers into `scratch` only: w.buf and w.jitter own nothing
     size_t carved = 0;
     carve_workspace(w, base + jitter_bytes, spp * npix, spp * npix, 1, nee, diffs, carved);
+    // one call at a time per GPU enqueues over the shared array, behind the previous call's work.  (A stream
+    // under capture can neither wait for an event recorded outside its capture nor lend one to later calls:
+    // there the caller orders the calls, as the graph's replays are the caller's to order anyway.)
+    std::lock_guard<std::mutex> dev_lk(g_scratch_call_mu[s->device]);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = st && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    if (!capturing && g_scratch_used[s->device]) HIP_TRY(hipStreamWaitEvent(st, g_scratch_done[s->device], 0));
     // What must start at zero is zeroed per batch on `st` (the segment counters, render_batches); the
     // rest of the array keeps the previous call's bytes, which no kernel reads before writing: queue
     // entries and hit records are only read below the counters of the same batch, and the bounce-0
@@ -1205,6 +1236,10 @@ int pt_render_device_noalloc(pt_scene* s, const pt_render_params* P_in, double* 
     rc = render_batches(s, P, accum_dev, st, w, (double*)base, spp, false, nee, diffs);
     s->timers_off = false;
     if (rc != PT_OK) return rc;
+    if (!capturing) {
+        HIP_TRY(hipEventRecord(g_scratch_done[s->device], st));
+        g_scratch_used[s->device] = true;
+    }
     s->stats.samples += n_asked;
     return PT_OK;
 }

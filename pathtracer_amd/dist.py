@@ -56,6 +56,9 @@ class Partition:
         self.ordered, self.row_group = ordered, row_group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # exchange() runs once per image: its row indices and staging buffers are made once per device
+        self._rows = {}     # (rank, device) -> int64 row indices on that device
+        self._stage = {}    # (name, shape, dtype, device) -> reusable tensor
 
     # ---- what this rank renders --------------------------------------------------------------------
     def rows_of(self, rank: int) -> torch.Tensor:
@@ -64,6 +67,19 @@ class Partition:
         if self.mode == "bands":
             return torch.arange(*split_range(self.height, self.world, rank), dtype=torch.int64)
         return torch.arange(self.height, dtype=torch.int64)
+
+    def _rows_on(self, rank: int, device) -> torch.Tensor:
+        key = (rank, str(device))
+        if key not in self._rows:
+            self._rows[key] = self.rows_of(rank).to(device)
+        return self._rows[key]
+
+    def _buffer(self, name: str, shape, like: torch.Tensor, device=None) -> torch.Tensor:
+        device = like.device if device is None else device
+        key = (name, tuple(shape), like.dtype, str(device))
+        if key not in self._stage:
+            self._stage[key] = torch.zeros(tuple(shape), dtype=like.dtype, device=device)
+        return self._stage[key]
 
     def pixels(self) -> int:
         """Pixels this rank renders per frame."""
@@ -92,29 +108,33 @@ class Partition:
 
     # ---- the one exchange --------------------------------------------------------------------------
     def _gather(self, t: torch.Tensor, dst: int = 0):
-        """dist.gather of equal-shaped tensors; gloo moves device tensors through the host."""
+        """dist.gather of equal-shaped tensors into reusable buffers; gloo moves device tensors through the host."""
         via_host = t.is_cuda and dist.get_backend(self.group) == "gloo"
         src = t.cpu() if via_host else t
-        parts = [torch.empty_like(src) for _ in range(self.world)] if self.rank == dst else None
+        parts = None
+        if self.rank == dst:
+            parts = [self._buffer(f"part{r}", src.shape, src, src.device) for r in range(self.world)]
         dist.gather(src, parts, dst=dst, group=self.group)
         if parts is not None and via_host:
             parts = [p.to(t.device) for p in parts]
         return parts
 
     def exchange(self, accum: torch.Tensor) -> torch.Tensor:
-        """Hands every rank's share to rank 0; ``accum`` is complete there afterwards."""
-        if self.world == 1:
+        """Hands every rank's share to rank 0; ``accum`` is complete there afterwards.  One call per image: an
+        image is done when rank 0 holds it."""
+        if self.world == 1 and not dist.is_initialized():
             return accum
         if self.mode in ("tiles", "bands"):
-            # every rank sends its own rows, packed and padded to the largest share: one gather
+            # every rank sends its own rows, packed and padded to the largest share: one gather (grouped
+            # point-to-point sends into rank 0 under RCCL: 7 xGMI links fan in, no ring)
             counts = [int(self.rows_of(r).numel()) for r in range(self.world)]
-            mine = self.rows_of(self.rank).to(accum.device)
-            band = torch.zeros((max(counts), self.width, 3), dtype=accum.dtype, device=accum.device)
-            band[: mine.numel()] = accum.index_select(0, mine)
+            mine = self._rows_on(self.rank, accum.device)
+            band = self._buffer("band", (max(counts), self.width, 3), accum)
+            torch.index_select(accum, 0, mine, out=band[: mine.numel()])
             parts = self._gather(band)
             if self.rank == 0:
                 for r in range(1, self.world):
-                    accum.index_copy_(0, self.rows_of(r).to(accum.device), parts[r][: counts[r]])
+                    accum.index_copy_(0, self._rows_on(r, accum.device), parts[r][: counts[r]])
         elif self.ordered:
             parts = self._gather(accum)
             if self.rank == 0:

@@ -18,8 +18,12 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pathtracer_amd.buildinfo import kernel_source_hashes  # noqa: E402
 
 KINDS = ("k_extend", "k_shade", "k_path", "k_shadow", "k_accumulate")
 N_SIMD = 1024.0
@@ -87,12 +91,15 @@ def main():
         return d
 
     res = {kind: derive(tot[kind], cnt[kind]) for kind in tot}
-    for kind in res:
+    for kind in list(res):
         res[kind]["correction"] = "FETCH_SIZE KiB x1024 x2 (gfx950 128-B requests tallied at 64 B), WRITE_SIZE KiB x1024; SQ cycle counters x4"
     try:
         allj = json.load(open(out_path))
     except (OSError, ValueError):
         allj = {}
+    # which device code the counters belong to: bench.py marks them stale when a kernel source has changed since
+    # (run this digest from the tree the passes were collected on)
+    res["_sources"] = kernel_source_hashes()
     allj[key] = res
     json.dump(allj, open(out_path, "w"), indent=1, sort_keys=True)
     print(f"# {key}: per kernel instantiation, per launch (scripts/pmc_digest.py)")

@@ -101,3 +101,39 @@ def test_noalloc_rejects_what_does_not_fit(gpu):
     scene.render_device(cfg, ref.data_ptr(), 0, 2)
     torch.cuda.synchronize()
     assert acc.cpu().numpy().tobytes() == ref.cpu().numpy().tobytes()
+
+
+def test_noalloc_two_scenes_on_two_streams_are_ordered(gpu):
+    # every call on a GPU shares that GPU's one static array, whatever scene or stream it comes from: the
+    # library orders them (per-device event), so two scenes alternating on two streams with no synchronisation
+    # in between give the images of the same calls made one at a time
+    import torch
+    torch.cuda.set_device(gpu)
+    a = pt.Scene(pt.scene_data("CornellBox"), device=gpu)
+    b = pt.Scene(pt.scene_data("glossy_planes"), device=gpu)
+    cfg_a = pt.Config(width=480, height=270, bounces=2, seed=4)
+    cfg_b = pt.Config(width=384, height=216, bounces=3, seed=6, nee=True, drop_nonfinite=True)
+    ref_a = torch.zeros((cfg_a.h, cfg_a.w, 3), dtype=torch.float64, device="cuda")
+    ref_b = torch.zeros((cfg_b.h, cfg_b.w, 3), dtype=torch.float64, device="cuda")
+    n_rounds, spp = 6, 3
+    for i in range(n_rounds):
+        a.render_device(cfg_a, ref_a.data_ptr(), spp * i, spp)
+        b.render_device(cfg_b, ref_b.data_ptr(), spp * i, spp)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    acc_a, acc_b = torch.zeros_like(ref_a), torch.zeros_like(ref_b)
+    torch.cuda.synchronize()
+    for i in range(n_rounds):                                  # enqueue only: nothing waits on the host in between
+        a.render_device_noalloc(cfg_a, acc_a.data_ptr(), spp * i, spp, stream=s1.cuda_stream)
+        b.render_device_noalloc(cfg_b, acc_b.data_ptr(), spp * i, spp, stream=s2.cuda_stream)
+    torch.cuda.synchronize()
+    assert ref_a.any().item() and ref_b.any().item()
+    assert acc_a.cpu().numpy().tobytes() == ref_a.cpu().numpy().tobytes()
+    assert acc_b.cpu().numpy().tobytes() == ref_b.cpu().numpy().tobytes()
+    # one scene on two streams as well
+    acc = torch.zeros_like(ref_a)
+    torch.cuda.synchronize()
+    for i in range(n_rounds):
+        a.render_device_noalloc(cfg_a, acc.data_ptr(), spp * i, spp, stream=(s1 if i % 2 else s2).cuda_stream)
+    torch.cuda.synchronize()
+    assert acc.cpu().numpy().tobytes() == ref_a.cpu().numpy().tobytes()
