@@ -264,12 +264,15 @@ typedef struct pt_scene_options {
     uint32_t wave_rays;      /* rays per vote-scheduled range: a power of two in 64..1024 (default 512) */
     uint32_t bvh_max_leaf;   /* triangles per leaf of the library's own BVH build, 1..8 (default 2) */
     uint32_t bvh_threads;    /* host threads of that build, 1..64 (default: the hardware's, at most 16) */
+    int8_t lds_top;          /* deep trees: the top of the four-wide tree (its first 21 nodes, breadth-first) is held in
+                              * LDS by every traversal wave (default on) */
+    int8_t reserved8[3];     /* 0 */
 } pt_scene_options;
 /* every field to its default */
 void pt_scene_options_init(pt_scene_options* options);
 /* ... then the overrides of the process environment, for tuning sweeps without a rebuild: PT_TRAV_VOTE_PRIMARY,
  * PT_TRAV_VOTE, PT_TRAV_VOTE_SHADOW, PT_FUSE, PT_FUSE_SHADOW, PT_LIGHT_CULL, PT_SCREEN_CULL, PT_PIPELINE,
- * PT_PERSISTENT, PT_EYE_TABLES, PT_LDS_SCENE = 0|1; PT_GROUP_FRAMES = 0..6; PT_WAVE_RAYS, PT_BVH_LEAF, PT_BVH_THREADS = counts.  This is the
+ * PT_PERSISTENT, PT_EYE_TABLES, PT_LDS_SCENE, PT_LDS_TOP = 0|1; PT_GROUP_FRAMES = 0..6; PT_WAVE_RAYS, PT_BVH_LEAF, PT_BVH_THREADS = counts.  This is the
  * only function of the library that reads the environment. */
 void pt_scene_options_from_env(pt_scene_options* options);
 

@@ -70,7 +70,8 @@ class pt_scene_options(C.Structure):
     _fields_ = [("struct_size", C.c_uint32)] + [(n, C.c_int8) for n in (
         "vote_primary", "vote_secondary", "vote_shadow", "fuse", "fuse_shadow", "light_cull", "screen_cull", "pipeline",
         "persistent", "eye_tables", "lds_scene", "group_frames")] + [
-        ("wave_rays", C.c_uint32), ("bvh_max_leaf", C.c_uint32), ("bvh_threads", C.c_uint32)]
+        ("wave_rays", C.c_uint32), ("bvh_max_leaf", C.c_uint32), ("bvh_threads", C.c_uint32),
+        ("lds_top", C.c_int8), ("reserved8", C.c_int8 * 3)]
 
 
 class pt_ray(C.Structure):

@@ -415,7 +415,7 @@ void pt_scene_options_init(pt_scene_options* o) {
     memset(o, 0, sizeof *o);
     o->struct_size = (uint32_t)sizeof *o;
     o->vote_primary = o->vote_secondary = o->vote_shadow = o->fuse = o->fuse_shadow = o->light_cull = o->screen_cull =
-        o->pipeline = o->persistent = o->eye_tables = o->lds_scene = o->group_frames = PT_OPT_DEFAULT;
+        o->pipeline = o->persistent = o->eye_tables = o->lds_scene = o->group_frames = o->lds_top = PT_OPT_DEFAULT;
 }
 
 void pt_scene_options_from_env(pt_scene_options* o) {
@@ -440,6 +440,7 @@ void pt_scene_options_from_env(pt_scene_options* o) {
     flag("PT_PERSISTENT", o->persistent);
     flag("PT_EYE_TABLES", o->eye_tables);
     flag("PT_LDS_SCENE", o->lds_scene);
+    flag("PT_LDS_TOP", o->lds_top);
     if (const char* e = getenv("PT_GROUP_FRAMES")) if (*e) o->group_frames = (int8_t)std::max(0, std::min(6, atoi(e)));
     count("PT_WAVE_RAYS", o->wave_rays);
     if (!valid_wave_rays(o->wave_rays)) o->wave_rays = 0;  // a sweep's bad value falls back to the default
@@ -578,7 +579,7 @@ static int scene_create_impl(const pt_scene_desc* d, int device_id, const pt_sce
     }
     int rc;
     if (s->depth > 8) {  // deep: the kernels walk four-wide nodes (pt_bvh.cpp bvh_collapse4)
-        rc = pth::bvh_collapse4(s->nodes, (uint32_t)ptd::kWideStack, s->nodes4, s->stack_need);
+        rc = pth::bvh_collapse4(s->nodes, (uint32_t)ptd::kWideStack, s->nodes4, s->stack_need, 85u /* three levels breadth-first: more than any build holds in LDS */);
         if (rc != PT_OK) { set_error("four-wide collapse failed: stack need %u > %d", s->stack_need, ptd::kWideStack); return rc; }
         if ((rc = upload(s->d_nodes4, s->nodes4.data(), s->nodes4.size())) != PT_OK) return rc;
     } else {
@@ -708,6 +709,9 @@ static int scene_create_impl(const pt_scene_desc* d, int device_id, const pt_sce
     dv.n_tris = d->n_tris;
     dv.n_lights = (uint32_t)lights.size();
     dv.bvh_depth = s->depth;
+    // (heightfield 10 M triangles, 0 / 5 / 21 / 28 / 32 / 48 nodes in LDS: 11.69 / 12.07 / 11.88-12.10 / 12.11 / 11.66 / 11.12
+    // Gsamples/s in one call: the root and its children carry the gain, more LDS per wave costs occupancy)
+    dv.n_top = opt(o.lds_top, true) ? std::min<uint32_t>((uint32_t)ptd::kTopNodes, (uint32_t)s->nodes4.size()) : 0u;
     resolve_scheduling(dv, o);
     {
         hipDeviceProp_t prop;

@@ -433,7 +433,8 @@ void bvh_widen(std::vector<pt_bvh_node>& nodes, const float* verts, uint32_t n_v
 // only while every child's height fits the entries left, h(child) <= b - (k - 1); the children then
 // inherit b - (k - 1).  By induction every subtree needs at most its b; the root's is `budget` and
 // bvh_validate has bounded the height by 32.  The actual need is returned for the statistics.
-int bvh_collapse4(const std::vector<pt_bvh_node>& nodes2, uint32_t budget, std::vector<pt_bvh_node4>& out, uint32_t& need_out) {
+int bvh_collapse4(const std::vector<pt_bvh_node>& nodes2, uint32_t budget, std::vector<pt_bvh_node4>& out, uint32_t& need_out,
+                  uint32_t top) {
     out.clear();
     need_out = 0;
     if (nodes2.empty()) return PT_OK;
@@ -523,6 +524,48 @@ int bvh_collapse4(const std::vector<pt_bvh_node>& nodes2, uint32_t budget, std::
         }
         n4.count = (uint32_t)k;
         out[it.out] = n4;
+    }
+    // Numbering: the first `top` nodes in breadth-first order (the levels every ray starts with: the kernels keep
+    // them in LDS), the subtrees below them depth-first, parent before children, a node's children side by side.
+    if (top > 1 && out.size() > 1) {
+        const uint32_t n = (uint32_t)out.size();
+        std::vector<uint32_t> order;  // order[new] = old
+        order.reserve(n);
+        std::vector<uint8_t> placed(n, 0);
+        order.push_back(0);
+        placed[0] = 1;
+        for (size_t head = 0; head < order.size() && order.size() < top; ++head)
+            for (int c = 0; c < 4 && order.size() < top; ++c) {
+                const int32_t ch = out[order[head]].child[c];
+                if (ch >= 0 && ch != PT_BVH_EMPTY) { order.push_back((uint32_t)ch); placed[ch] = 1; }
+            }
+        const size_t n_top = order.size();
+        std::vector<uint32_t> st;
+        for (size_t t = 0; t < n_top; ++t) {  // the subtrees hanging below the top, in the order of their parents
+            for (int c = 3; c >= 0; --c) {
+                const int32_t ch = out[order[t]].child[c];
+                if (ch >= 0 && ch != PT_BVH_EMPTY && !placed[ch]) st.push_back((uint32_t)ch);
+            }
+            while (!st.empty()) {
+                const uint32_t i = st.back();
+                st.pop_back();
+                order.push_back(i);
+                placed[i] = 1;
+                for (int c = 3; c >= 0; --c) {
+                    const int32_t ch = out[i].child[c];
+                    if (ch >= 0 && ch != PT_BVH_EMPTY) st.push_back((uint32_t)ch);
+                }
+            }
+        }
+        std::vector<uint32_t> new_of(n);
+        for (uint32_t k = 0; k < n; ++k) new_of[order[k]] = k;
+        std::vector<pt_bvh_node4> re(n);
+        for (uint32_t k = 0; k < n; ++k) {
+            re[k] = out[order[k]];
+            for (int c = 0; c < 4; ++c)
+                if (re[k].child[c] >= 0 && re[k].child[c] != PT_BVH_EMPTY) re[k].child[c] = (int32_t)new_of[re[k].child[c]];
+        }
+        out.swap(re);
     }
     // actual stack need: children have larger indices than their parent
     need.assign(out.size(), 0);

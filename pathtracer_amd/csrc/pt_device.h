@@ -137,6 +137,7 @@ struct Scene {
     const Prim* prims;  // tested against every ray before the tree is walked; hit id PT_PRIM_BASE + k
     uint32_t n_prims;
     uint32_t n_nodes, n_tris, n_lights, bvh_depth;
+    uint32_t n_top;  // nodes4[0 .. n_top) are the top of the tree, breadth-first: held in LDS by the traversal kernels (<= kTopNodes; 0 = off)
     double light_area;
     uint32_t mat_features;  // bit 0: some material has a texture; bit 1: some is Glossy / Mirror / Transparent
                             // (selects the shade code compiled in: 0 = the lean untextured-Lambertian kernels)
@@ -309,6 +310,15 @@ constexpr int kStackDepth = 32;  // deepest two-child tree accepted (bvh_validat
 // kWideStack = kWideLds entries in LDS + kWideSpill in private memory (touched only by the rare ray that
 // goes beyond 16).
 constexpr int kWideLds = 16, kWideSpill = 48, kWideStack = kWideLds + kWideSpill;
+// The top of a four-wide tree in LDS: every ray starts at the root and spends its first two or three node steps
+// among the same few nodes, so the first kTopNodes nodes in breadth-first order (bvh_collapse4 numbers them first:
+// the root, its children, their children = 1 + 4 + 16) are copied into LDS by every wave of a traversal kernel and
+// read from there (ds_read_b128 instead of a trip through the texture addresser and the vector L1).  Same boxes,
+// same order: hit ids and distances do not change.  2688 B per wave beside its 4 KB stack.
+#ifndef PT_TOP_NODES
+#define PT_TOP_NODES 21
+#endif
+constexpr int kTopNodes = PT_TOP_NODES;
 constexpr int kBlock = 256;
 constexpr int kTravBlock = 64;  // extend / shadow: one wave per workgroup, LDS and registers are released per wave
 

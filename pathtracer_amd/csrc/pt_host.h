@@ -28,7 +28,9 @@ const char* last_error();
 // pt_bvh.cpp
 int bvh_build(const float* verts, uint32_t n_verts, const uint32_t* tris, uint32_t n_tris, uint32_t max_leaf,
               std::vector<pt_bvh_node>& out_nodes, std::vector<uint32_t>& out_order, uint32_t& out_depth, uint32_t n_threads = 0);
-int bvh_collapse4(const std::vector<pt_bvh_node>& nodes2, uint32_t budget, std::vector<pt_bvh_node4>& out, uint32_t& need_out);
+// `top`: the first `top` nodes of `out` are the top of the tree in breadth-first order (held in LDS by the kernels)
+int bvh_collapse4(const std::vector<pt_bvh_node>& nodes2, uint32_t budget, std::vector<pt_bvh_node4>& out, uint32_t& need_out,
+                  uint32_t top = 0);
 void bvh_widen(std::vector<pt_bvh_node>& nodes, const float* verts, uint32_t n_verts);
 int bvh_validate(const pt_bvh_node* nodes, uint32_t n_nodes, const uint32_t* order, uint32_t n_tris,
                  uint32_t stack_depth, uint32_t& depth_out, std::string& why);

@@ -908,6 +908,9 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), ((MATS & 1) ? PT_TE
                                                  Counters* ctr) {
     constexpr int kPathBlock = PathBlock<DEPTH, LDS>::value;
     __shared__ int stack[DEPTH * kPathBlock];
+    __shared__ float4 s_top[(DEPTH > 8 && kTopNodes > 0) ? kTopNodes * 8 : 1];
+    TopNodes top{nullptr, 0};
+    if (DEPTH > 8 && kTopNodes > 0) top = load_top_nodes<kPathBlock>(gsc, s_top);
     __shared__ uint32_t lds_a[kPathBlock / 64 + 1];
     __shared__ uint32_t lds_b[kPathBlock / 64 + 1];
     __shared__ float4 s_nodes[LDS ? kLdsScene * 4 : 1];
@@ -1007,7 +1010,7 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), ((MATS & 1) ? PT_TE
             uint32_t leaf = PT_MISS;
             if (on_screen)
                 leaf = (FIRST && (LDS || sc.eye_nodes)) ? traverse_eye<DEPTH, kPathBlock>(sc, d, 1e-5, t, stack + threadIdx.x)
-                                               : traverse<DEPTH, false, false, kPathBlock, LDS>(sc, o, d, 1e-5, t, stack + threadIdx.x, nn, nt);
+                                               : traverse<DEPTH, false, false, kPathBlock, LDS>(sc, o, d, 1e-5, t, stack + threadIdx.x, nn, nt, top);
             shade_vertex<FIRST, LAST, NEE, MATS, true>(sc, fr, bounce, in, i, rec, leaf, t, o, d, ls, r);
             if (NEE && !LAST && sc.fuse_shadow && r.shadow) {
                 // the light sample's visibility, in place: the shadow ray never leaves the registers
@@ -1015,7 +1018,7 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), ((MATS & 1) ? PT_TE
                 // of additions as the shadow kernel's: the vertex's emission first, then its light sample.
                 double st_max = r.s_tmax;
                 uint32_t nn2 = 0, nt2 = 0;
-                if (traverse<DEPTH, true, false, kPathBlock, LDS>(sc, r.n_o, r.s_d, 1e-5, st_max, stack + threadIdx.x, nn2, nt2) == PT_MISS) {
+                if (traverse<DEPTH, true, false, kPathBlock, LDS>(sc, r.n_o, r.s_d, 1e-5, st_max, stack + threadIdx.x, nn2, nt2, top) == PT_MISS) {
                     if (FIRST) {
                         double* c = ls.c + (size_t)r.slot * 3;
                         if (r.lit) { c[0] += r.s_c.x; c[1] += r.s_c.y; c[2] += r.s_c.z; }

@@ -224,10 +224,26 @@ __device__ __forceinline__ int node_step(const Scene& sc, int cur, const RayF& r
 // The stack of a wide traversal: kWideLds entries in LDS ([entry][lane], as above), the rest in a private
 // array that only a ray with more than kWideLds pending subtrees touches.  bvh_collapse4 bounds the need
 // by kWideStack for every tree that passed bvh_validate.
+typedef float V4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const V4f* LdsF4;  // a pointer the compiler knows to be LDS (ds_read_b128, not flat)
+__device__ __forceinline__ float4 ldsf4(LdsF4 p, int k) { const V4f v = p[k]; return make_float4(v.x, v.y, v.z, v.w); }
+struct TopNodes {   // Scene::nodes4[0 .. n) copied into LDS (pt_device.h kTopNodes)
+    LdsF4 p;
+    int n;
+};
 struct WideStack {
     int* lds;     // this lane's column: entry e at lds[e * STRIDE]
     int* spill;   // kWideSpill private entries
+    TopNodes top;
 };
+// all threads of the workgroup, before any of them leaves; BLOCK threads
+template <int BLOCK>
+__device__ __forceinline__ TopNodes load_top_nodes(const Scene& sc, float4* s_top) {
+    const int n = min((int)sc.n_top, kTopNodes);
+    for (int k = threadIdx.x; k < n * 8; k += BLOCK) s_top[k] = sc.nodes4[k];
+    __syncthreads();
+    return TopNodes{(LdsF4)(V4f*)s_top, n};
+}
 template <int STRIDE>
 __device__ __forceinline__ void wide_push(const WideStack& st, int& sp, int ref) {
     PT_STACK_CHECK(sp, kWideStack);
@@ -251,9 +267,14 @@ __device__ __forceinline__ int wide_pop(const WideStack& st, int& sp) {
 template <bool STATS, int STRIDE>
 __device__ __forceinline__ int node4_step(const Scene& sc, int cur, const RayF& rf, float t_min, float t_max,
                                           const WideStack& st, int& sp, uint32_t& n_nodes) {
-    const float4* np = sc.nodes4 + (size_t)cur * 8;
-    const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5];
-    const float4 cf = np[6];
+    float4 lx, ly, lz, hx, hy, hz, cf;
+    if (kTopNodes > 0 && cur < st.top.n) {  // the top of the tree lives in LDS
+        LdsF4 np = st.top.p + cur * 8;
+        lx = ldsf4(np, 0); ly = ldsf4(np, 1); lz = ldsf4(np, 2); hx = ldsf4(np, 3); hy = ldsf4(np, 4); hz = ldsf4(np, 5); cf = ldsf4(np, 6);
+    } else {
+        const float4* np = sc.nodes4 + (size_t)cur * 8;
+        lx = np[0]; ly = np[1]; lz = np[2]; hx = np[3]; hy = np[4]; hz = np[5]; cf = np[6];
+    }
     const int c[4] = {__float_as_int(cf.x), __float_as_int(cf.y), __float_as_int(cf.z), __float_as_int(cf.w)};
     const float lox[4] = {lx.x, lx.y, lx.z, lx.w}, loy[4] = {ly.x, ly.y, ly.z, ly.w}, loz[4] = {lz.x, lz.y, lz.z, lz.w};
     const float hix[4] = {hx.x, hx.y, hx.z, hx.w}, hiy[4] = {hy.x, hy.y, hy.z, hy.w}, hiz[4] = {hz.x, hz.y, hz.z, hz.w};
@@ -354,10 +375,10 @@ struct RangePool {
 
 template <int DEPTH, bool ANY, bool STATS, class Fetch, class Done>
 __device__ __forceinline__ void trace_range_vote(const Scene& sc, uint32_t begin, uint32_t end, RangePool pool, int* stk,
-                                                 Fetch fetch, Done done, uint32_t& n_nodes, uint32_t& n_tris) {
+                                                 TopNodes top, Fetch fetch, Done done, uint32_t& n_nodes, uint32_t& n_tris) {
     constexpr bool WIDE = DEPTH > 8;  // deep trees are walked through their four-wide nodes
     int spill[WIDE ? kWideSpill : 1];
-    const WideStack wst{stk, spill};
+    const WideStack wst{stk, spill, top};
     uint32_t cursor = begin;  // wave-uniform: first unclaimed ray
     bool more = pool.cursors != nullptr;  // wave-uniform: the pool may hold further ranges
     bool busy = false;
@@ -455,7 +476,7 @@ __device__ __forceinline__ void trace_range_vote(const Scene& sc, uint32_t begin
 // EDGES: the triangle test starts from Scene::tri_edges instead of the vertices (the scene-in-LDS kernel).
 template <int DEPTH, bool ANY, bool STATS, int STRIDE = kTravBlock, bool EDGES = false>
 __device__ __forceinline__ uint32_t traverse(const Scene& sc, D3 o, D3 d, double t_min, double& t_max, int* stk,
-                                             uint32_t& n_nodes, uint32_t& n_tris) {
+                                             uint32_t& n_nodes, uint32_t& n_tris, TopNodes top = TopNodes{nullptr, 0}) {
     uint32_t best = PT_MISS, best_id = PT_MISS;
     if (sc.n_prims) {
         prims_closest(sc, o, d, t_min, t_max, best, best_id);
@@ -464,7 +485,7 @@ __device__ __forceinline__ uint32_t traverse(const Scene& sc, D3 o, D3 d, double
     if (sc.n_nodes == 0) return best;
     constexpr bool WIDE = DEPTH > 8;
     int spill[WIDE ? kWideSpill : 1];
-    const WideStack wst{stk, spill};
+    const WideStack wst{stk, spill, top};
     const RayF rf = make_rayf(o, d);
     const float t_min32 = f32_down(t_min);
     float t_max32 = f32_up(t_max);
@@ -686,6 +707,9 @@ __global__ __launch_bounds__(kTravBlock, PT_TRAV_WAVES) void k_extend(Scene sc, 
                                                    const double* __restrict__ tmax, Live live, uint32_t wave_rays,
                                                    Hits hits, Counters* ctr) {
     __shared__ int stack[DEPTH * kTravBlock];
+    __shared__ float4 s_top[(DEPTH > 8 && kTopNodes > 0) ? kTopNodes * 8 : 1];
+    TopNodes top{nullptr, 0};
+    if (DEPTH > 8 && kTopNodes > 0) top = load_top_nodes<kTravBlock>(sc, s_top);
     if (ctr && blockIdx.x == 0 && threadIdx.x == 0)
         atomicAdd(&ctr->rays, PRIMARY ? (unsigned long long)fr.n_on_screen * fr.n_samples : live_total(live));
     // wave w of the launch owns the wave_rays queue entries [w, w + 1) * wave_rays
@@ -741,7 +765,7 @@ __global__ __launch_bounds__(kTravBlock, PT_TRAV_WAVES) void k_extend(Scene sc, 
 #ifdef PT_DEBUG_TAIL
         unsigned long long dbg_t0 = wall_clock64();
 #endif
-        trace_range_vote<DEPTH, false, STATS>(sc, begin, end, pool, stack + threadIdx.x, fetch, done, nn, nt);
+        trace_range_vote<DEPTH, false, STATS>(sc, begin, end, pool, stack + threadIdx.x, top, fetch, done, nn, nt);
 #ifdef PT_DEBUG_TAIL
         if (!STATS && live.cursors && lane == 0 && blockIdx.x < 8192) { g_dbg_tail[2 * blockIdx.x] = dbg_t0; g_dbg_tail[2 * blockIdx.x + 1] = wall_clock64(); }
 #endif
@@ -751,7 +775,7 @@ __global__ __launch_bounds__(kTravBlock, PT_TRAV_WAVES) void k_extend(Scene sc, 
         double t_min, t_max;
         fetch(i, o, d, t_min, t_max);
         if (PRIMARY && t_max < 0.) done(i, PT_MISS, t_max);  // off screen
-        else done(i, traverse<DEPTH, false, STATS>(sc, o, d, t_min, t_max, stack + threadIdx.x, nn, nt), t_max);
+        else done(i, traverse<DEPTH, false, STATS>(sc, o, d, t_min, t_max, stack + threadIdx.x, nn, nt, top), t_max);
     }
     if (STATS) {
         // wave-level reduction, one atomic pair per wave
@@ -783,6 +807,9 @@ template <int DEPTH, bool VOTE>
 __global__ __launch_bounds__(kTravBlock, PT_TRAV_WAVES) void k_shadow(Scene sc, ShadowQueue sq, Live live, uint32_t wave_rays, Sample3 ls,
                                                    Counters* ctr) {
     __shared__ int stack[DEPTH * kTravBlock];
+    __shared__ float4 s_top[(DEPTH > 8 && kTopNodes > 0) ? kTopNodes * 8 : 1];
+    TopNodes top{nullptr, 0};
+    if (DEPTH > 8 && kTopNodes > 0) top = load_top_nodes<kTravBlock>(sc, s_top);
     if (ctr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->shadow_rays, live_total(live));
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t begin, end;
@@ -810,13 +837,13 @@ __global__ __launch_bounds__(kTravBlock, PT_TRAV_WAVES) void k_shadow(Scene sc, 
             radiance_add(ls, sq.slot[i], mk(sq.c[0][i], sq.c[1][i], sq.c[2][i]));
         };
     if (VOTE) {
-        trace_range_vote<DEPTH, true, false>(sc, begin, end, pool, stack + threadIdx.x, fetch, done, nn, nt);
+        trace_range_vote<DEPTH, true, false>(sc, begin, end, pool, stack + threadIdx.x, top, fetch, done, nn, nt);
     } else if (begin + lane < end) {  // wave_rays == 64
         uint32_t i = begin + lane;
         D3 o, d;
         double t_min, t_max;
         fetch(i, o, d, t_min, t_max);
-        done(i, traverse<DEPTH, true, false>(sc, o, d, t_min, t_max, stack + threadIdx.x, nn, nt), t_max);
+        done(i, traverse<DEPTH, true, false>(sc, o, d, t_min, t_max, stack + threadIdx.x, nn, nt, top), t_max);
     }
 }
 

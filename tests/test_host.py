@@ -37,7 +37,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(L.pt_material) == 40
     assert C.sizeof(L.pt_render_params) == 80
     assert C.sizeof(L.pt_camera) == 80
-    assert C.sizeof(L.pt_scene_options) == 28
+    assert C.sizeof(L.pt_scene_options) == 32
     assert C.sizeof(L.pt_area_light) == 56
 
 
@@ -45,7 +45,7 @@ def test_scene_options_defaults_environment_and_validation(monkeypatch):
     o = L.pt_scene_options()
     L.lib.pt_scene_options_init(C.byref(o))
     flags = [n for n, t in L.pt_scene_options._fields_ if t is C.c_int8]
-    assert o.struct_size == 28 and all(getattr(o, n) == -1 for n in flags)
+    assert o.struct_size == 32 and all(getattr(o, n) == -1 for n in flags)
     assert (o.wave_rays, o.bvh_max_leaf, o.bvh_threads) == (0, 0, 0)
     # the environment is read by pt_scene_options_from_env alone (the sweeps' hook, what pt_scene_create uses)
     for k, v in (("PT_FUSE", "0"), ("PT_TRAV_VOTE", "1"), ("PT_WAVE_RAYS", "128"), ("PT_BVH_LEAF", "4"), ("PT_LDS_SCENE", "0")):
