@@ -217,6 +217,7 @@ void resolve_scheduling(ptd::Scene& dv, const pt_scene_options& o) {
     dv.vote_shadow = opt(o.vote_shadow, deep);
     dv.fuse = opt(o.fuse, true);
     dv.fuse_shadow = opt(o.fuse_shadow, true) && dv.fuse;
+    dv.fuse01 = 0;  // set once the scene is on the device (scene_create_impl: needs lds_scene and a probe of the primary rays)
     // (128 / 256 / 512 / 1024 -> 8.73 / 9.17 / 9.29 / 9.3 Gsamples/s on the 10 M-triangle scene)
     dv.wave_rays = o.wave_rays ? o.wave_rays : 512;
 }
@@ -415,7 +416,7 @@ void pt_scene_options_init(pt_scene_options* o) {
     memset(o, 0, sizeof *o);
     o->struct_size = (uint32_t)sizeof *o;
     o->vote_primary = o->vote_secondary = o->vote_shadow = o->fuse = o->fuse_shadow = o->light_cull = o->screen_cull =
-        o->pipeline = o->persistent = o->eye_tables = o->lds_scene = o->group_frames = o->lds_top = PT_OPT_DEFAULT;
+        o->pipeline = o->persistent = o->eye_tables = o->lds_scene = o->group_frames = o->lds_top = o->fuse01 = PT_OPT_DEFAULT;
 }
 
 void pt_scene_options_from_env(pt_scene_options* o) {
@@ -441,6 +442,7 @@ void pt_scene_options_from_env(pt_scene_options* o) {
     flag("PT_EYE_TABLES", o->eye_tables);
     flag("PT_LDS_SCENE", o->lds_scene);
     flag("PT_LDS_TOP", o->lds_top);
+    flag("PT_FUSE01", o->fuse01);
     if (const char* e = getenv("PT_GROUP_FRAMES")) if (*e) o->group_frames = (int8_t)std::max(0, std::min(6, atoi(e)));
     count("PT_WAVE_RAYS", o->wave_rays);
     if (!valid_wave_rays(o->wave_rays)) o->wave_rays = 0;  // a sweep's bad value falls back to the default
@@ -455,6 +457,7 @@ int pt_scene_create(const pt_scene_desc* d, int device_id, pt_scene** out) {
 }
 
 static int scene_create_impl(const pt_scene_desc* d, int device_id, const pt_scene_options* options, pt_scene** out);
+namespace { void screen_bounds(const pt_scene* s, uint32_t width, uint32_t height, ptd::Frame& fr); }
 // No exception crosses the C ABI: a scene of 10 M triangles needs ~2 GB of host memory while it is built.
 int pt_scene_create_ex(const pt_scene_desc* d, int device_id, const pt_scene_options* options, pt_scene** out) {
     try {
@@ -782,6 +785,35 @@ static int scene_create_impl(const pt_scene_desc* d, int device_id, const pt_sce
     }
     HIP_TRY(hipDeviceSynchronize());
     for (int a = 0; a < 3; ++a) dv.background[a] = d->background[a];
+    // Bounces 0 and 1 in one kernel (k_path F01) pays when nearly every primary ray hits something - a lane whose
+    // path ended at its first vertex idles through the second.  Probe: the primary rays of a 64 x 64 image (frame
+    // jitter 0) inside the scene's screen bounds, traced on the device; on from 50 % hits.  (Measured: CornellBox,
+    // every primary ray inside the bounds hits, 31.8 -> 38.5 Gsamples/s; glossy_planes, 9.71 -> 12.02.)
+    dv.fuse01 = 0;
+    if (dv.lds_scene && o.fuse01 != 0) {
+        dv.fuse01 = 1;
+        if (o.fuse01 < 0) {
+            ptd::Frame fr{};
+            fr.width = fr.height = fr.tile_w = fr.tile_h = 64;
+            fr.n_tile_pixels = 64 * 64;
+            fr.n_samples = 1;
+            DevBuf jit, tri, tt;
+            HIP_TRY(jit.alloc(2 * sizeof(double)));
+            HIP_TRY(hipMemset(jit.p, 0, 2 * sizeof(double)));
+            HIP_TRY(tri.alloc(fr.n_tile_pixels * sizeof(uint32_t)));
+            HIP_TRY(tt.alloc(fr.n_tile_pixels * sizeof(double)));
+            fr.jitter = jit.as<double>();
+            screen_bounds(s.get(), 64, 64, fr);
+            ptd::finish_frame(fr);
+            ptd::launch_extend_primary(dv, fr, ptd::Hits{tri.as<uint32_t>(), tt.as<double>()}, nullptr, false, nullptr);
+            HIP_TRY(hipGetLastError());
+            std::vector<uint32_t> hit(fr.n_tile_pixels);
+            HIP_TRY(hipMemcpy(hit.data(), tri.p, hit.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            size_t n_hit = 0;
+            for (uint32_t v : hit) n_hit += v != PT_MISS;
+            dv.fuse01 = fr.n_on_screen > 0 && n_hit * 2 >= (size_t)fr.n_on_screen;
+        }
+    }
 
     *out = s.release();
     return PT_OK;
@@ -944,6 +976,21 @@ int render_batches(pt_scene* s, const pt_render_params* P, double* accum_dev, hi
         if (bounce == 0) ptd::launch_extend_primary(s->dev, r.fr, r.ln->hits, ctr, stats, r.st);
         else ptd::launch_extend(s->dev, r.ln->q[bounce & 1], nullptr, nullptr, live, r.ln->hits, ctr, stats, r.st);
     };
+    // the primary launch of a scene in LDS takes the second vertex along: bounces 0 and 1 in one kernel
+    auto run_two = [&](LaneRun& r) {
+        uint32_t* path_cnt = r.ln->counters;
+        uint32_t* shad_cnt = r.ln->counters + kCounterSets * kSetWords;
+        ptd::Live live{nullptr, 0, r.n_max, nullptr};
+        ptd::Push mid{path_cnt + 1 * kSetWords, r.seg};    // counts the rays of bounce 1 (statistics)
+        ptd::Push push{path_cnt + 2 * kSetWords, r.seg};   // the queue of bounce 2
+        ptd::Push spush{shad_cnt, r.seg};
+        {
+            Timer t(s, r.st, PT_K_PATH);
+            ptd::launch_path(s->dev, r.fr, 0, r.ln->q[0], live, r.ln->q[0], push, r.ln->sq, spush, r.ls, ctr, r.st, mid);
+        }
+        ptd::launch_count_rays(mid.counts, ctr, r.st);
+        if (nee) ptd::launch_count_shadow_rays(spush.counts, ctr, r.st);
+    };
     auto run_shade = [&](LaneRun& r, uint32_t bounce, bool fused) {
         uint32_t* path_cnt = r.ln->counters;
         uint32_t* shad_cnt = r.ln->counters + kCounterSets * kSetWords;
@@ -1019,9 +1066,11 @@ int render_batches(pt_scene* s, const pt_render_params* P, double* accum_dev, hi
             r.seg = ptd::seg_size_for(r.n_max);  // <= the size the lane was carved for
             r.cap = ptd::kSegs * r.seg;
         }
+        const bool two_bounces = !stats && !diffs && ptd::path_two_bounces(s->dev, run[0].fr);
         if (n_run == 1) {
             HIP_TRY(hipMemsetAsync(run[0].ln->counters, 0, kCounterWords * sizeof(uint32_t), st));
-            for (uint32_t bounce = 0; bounce <= P->max_bounces; ++bounce) {
+            if (two_bounces) run_two(run[0]);
+            for (uint32_t bounce = two_bounces ? 2 : 0; bounce <= P->max_bounces; ++bounce) {
                 const bool fused = can_fuse(bounce);
                 if (!fused) run_extend(run[0], bounce);
                 run_shade(run[0], bounce, fused);
@@ -1037,7 +1086,8 @@ int render_batches(pt_scene* s, const pt_render_params* P, double* accum_dev, hi
             HIP_TRY(hipStreamWaitEvent(sd, ev[0], 0));
             HIP_TRY(hipMemsetAsync(run[0].ln->counters, 0, kCounterWords * sizeof(uint32_t), st));
             HIP_TRY(hipMemsetAsync(run[1].ln->counters, 0, kCounterWords * sizeof(uint32_t), sd));
-            for (uint32_t bounce = 0; bounce <= P->max_bounces; ++bounce) {
+            if (two_bounces) { run_two(run[0]); run_two(run[1]); }
+            for (uint32_t bounce = two_bounces ? 2 : 0; bounce <= P->max_bounces; ++bounce) {
                 const bool fused = can_fuse(bounce);
                 if (!fused) run_extend(run[0], bounce);
                 if (!fused) run_extend(run[1], bounce);

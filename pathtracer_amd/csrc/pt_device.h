@@ -148,6 +148,7 @@ struct Scene {
     uint8_t lds_scene;  // the scene is small enough to live in LDS inside the fused kernel (k_path LDS)
     uint32_t n_mats;
     uint8_t fuse_shadow;  // ... and the bounce's light sample traced in that kernel too
+    uint8_t fuse01;       // ... and the primary launch of a scene in LDS takes the path's second vertex along (k_path F01)
     uint32_t wave_rays;
     uint32_t n_cu;  // compute units of the device (size of a persistent launch)
     Camera cam;
@@ -334,8 +335,12 @@ void launch_shadow(const Scene& sc, ShadowQueue sq, Live live, Sample3 lsample, 
 // fused extend + shade of one bounce; false if this scene / bounce has no fused form (caller then
 // launches extend and shade)
 bool path_fusable(const Scene& sc, uint32_t bounce);
+// mid_push.counts != nullptr (bounce 0 only, path_two_bounces()): the launch traces bounces 0 and 1, `out` / `out_push`
+// are the queue of bounce 2 and mid_push's counters receive the number of bounce-1 rays
+bool path_two_bounces(const Scene& sc, const Frame& fr);
 bool launch_path(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, Live live, Queue out, Push out_push,
-                 ShadowQueue sq, Push sq_push, Sample3 lsample, Counters* ctr, hipStream_t st);
+                 ShadowQueue sq, Push sq_push, Sample3 lsample, Counters* ctr, hipStream_t st, Push mid_push = Push{nullptr, 0});
+void launch_count_rays(const uint32_t* seg_counts, Counters* ctr, hipStream_t st);
 // lsample.c covers every frame of the batch; frames [0, split) have their bits in lsample.lit, the
 // rest (the second lane's) in lit1, both indexed from the lane's first frame
 // the fused path kernel traced its own shadow rays (Scene::fuse_shadow) and left their number in the

@@ -191,9 +191,20 @@ void launch_shade(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, H
 template <int DEPTH, bool FIRST, bool LAST>
 static void launch_path_t(bool nee, dim3 g, dim3 b, hipStream_t st, const Scene& sc, const Frame& fr, uint32_t bounce,
                           Queue in, Live live, Queue out, Push out_push, ShadowQueue sq, Push sq_push, Sample3 ls,
-                          Counters* ctr) {
-#define PT_PATHK(N, M) hipLaunchKernelGGL((k_path<DEPTH, FIRST, LAST, N, M>), g, b, 0, st, sc, fr, bounce, in, live, out, out_push, sq, sq_push, ls, ctr)
-#define PT_PATHL(N, M) hipLaunchKernelGGL((k_path<8, FIRST, false, N, M, true>), g, b, 0, st, sc, fr, bounce, in, live, out, out_push, sq, sq_push, ls, ctr)
+                          Counters* ctr, Push mid_push) {
+#define PT_PATHK(N, M) hipLaunchKernelGGL((k_path<DEPTH, FIRST, LAST, N, M>), g, b, 0, st, sc, fr, bounce, in, live, out, out_push, sq, sq_push, ls, ctr, mid_push)
+#define PT_PATHL(N, M) hipLaunchKernelGGL((k_path<8, FIRST, false, N, M, true>), g, b, 0, st, sc, fr, bounce, in, live, out, out_push, sq, sq_push, ls, ctr, mid_push)
+#define PT_PATH2(N, M) hipLaunchKernelGGL((k_path<8, true, false, N, M, true, true>), g, b, 0, st, sc, fr, bounce, in, live, out, out_push, sq, sq_push, ls, ctr, mid_push)
+    if (DEPTH == 8 && FIRST && !LAST && sc.lds_scene && mid_push.counts) {  // bounces 0 and 1 in one go
+        switch (sc.mat_features & 3u) {
+            case 0: if (nee) PT_PATH2(true, 0); else PT_PATH2(false, 0); break;
+            case 1: if (nee) PT_PATH2(true, 1); else PT_PATH2(false, 1); break;
+            case 2: if (nee) PT_PATH2(true, 2); else PT_PATH2(false, 2); break;
+            default: if (nee) PT_PATH2(true, 3); else PT_PATH2(false, 3);
+        }
+        return;
+    }
+#undef PT_PATH2
     if (DEPTH == 8 && !LAST && sc.lds_scene) {  // tiny scene held in LDS
         switch (sc.mat_features & 3u) {
             case 0: if (nee) PT_PATHL(true, 0); else PT_PATHL(false, 0); break;
@@ -218,8 +229,14 @@ bool path_fusable(const Scene& sc, uint32_t bounce) {
     if (!sc.fuse) return false;
     return bounce == 0 ? !sc.vote_primary : (sc.bvh_depth <= 8 && !sc.vote_secondary);
 }
+// The primary launch may take the path's second vertex along (k_path F01): a scene that lives in LDS, whose
+// primary rays nearly all hit (Scene::fuse01), at least two bounces, light samples (if any) traced in the kernel.
+bool path_two_bounces(const Scene& sc, const Frame& fr) {
+    return sc.fuse01 && sc.lds_scene && sc.bvh_depth <= 8 && fr.max_bounces >= 2 && path_fusable(sc, 0) && path_fusable(sc, 1) &&
+           (!samples_lights(sc, fr.flags) || sc.fuse_shadow);
+}
 bool launch_path(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, Live live, Queue out, Push out_push,
-                 ShadowQueue sq, Push sq_push, Sample3 ls, Counters* ctr, hipStream_t st) {
+                 ShadowQueue sq, Push sq_push, Sample3 ls, Counters* ctr, hipStream_t st, Push mid_push) {
     if (!path_fusable(sc, bounce)) return false;
     if (!live.n) return true;
     bool nee = samples_lights(sc, fr.flags);
@@ -232,7 +249,7 @@ bool launch_path(const Scene& sc, const Frame& fr, uint32_t bounce, Queue in, Li
         live.sparse = 1;
         g.x = std::min(g.x, sc.n_cu * 8u);
     }
-    #define PT_PATH(D, F, L) launch_path_t<D, F, L>(nee, g, b, st, sc, fr, bounce, in, live, out, out_push, sq, sq_push, ls, ctr)
+    #define PT_PATH(D, F, L) launch_path_t<D, F, L>(nee, g, b, st, sc, fr, bounce, in, live, out, out_push, sq, sq_push, ls, ctr, mid_push)
     if (sc.bvh_depth <= 8) {
         if (first && last) PT_PATH(8, true, true);
         else if (first) PT_PATH(8, true, false);
@@ -257,14 +274,17 @@ void launch_shadow(const Scene& sc, ShadowQueue sq, Live live, Sample3 ls, Count
     if (sc.vote_shadow) launch_shadow_v<true>(sc, sq, live, sc.wave_rays, ls, ctr, st);
     else launch_shadow_v<false>(sc, sq, live, 64, ls, ctr, st);
 }
-__global__ void k_count_shadow_rays(const uint32_t* seg_counts, Counters* ctr) {
+__global__ void k_count_shadow_rays(const uint32_t* seg_counts, Counters* ctr, bool rays) {
     unsigned long long n = seg_counts[threadIdx.x * kCtrStride];  // kSegs threads
 #pragma unroll
     for (int d = 32; d; d >>= 1) n += __shfl_down(n, d);
-    if (threadIdx.x == 0 && n) atomicAdd(&ctr->shadow_rays, n);
+    if (threadIdx.x == 0 && n) atomicAdd(rays ? &ctr->rays : &ctr->shadow_rays, n);
 }
 void launch_count_shadow_rays(const uint32_t* seg_counts, Counters* ctr, hipStream_t st) {
-    hipLaunchKernelGGL(k_count_shadow_rays, dim3(1), dim3(kSegs), 0, st, seg_counts, ctr);
+    hipLaunchKernelGGL(k_count_shadow_rays, dim3(1), dim3(kSegs), 0, st, seg_counts, ctr, false);
+}
+void launch_count_rays(const uint32_t* seg_counts, Counters* ctr, hipStream_t st) {
+    hipLaunchKernelGGL(k_count_shadow_rays, dim3(1), dim3(kSegs), 0, st, seg_counts, ctr, true);
 }
 void launch_accumulate(const Frame& fr, Sample3 ls, const unsigned long long* lit1, uint32_t split, double* accum,
                        Counters* ctr, hipStream_t st) {

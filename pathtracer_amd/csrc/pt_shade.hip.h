@@ -545,6 +545,7 @@ __global__ void k_build_emitters(Scene sc, const uint32_t* leaf, uint32_t n, Emi
 //           the scene has only untextured Lambertian materials: the Glossy and texture code is
 //           compiled out, which is what keeps this kernel's register count (and occupancy) sane.
 //   FUSED = o, d hold the ray (the caller traced it); otherwise they are loaded here when needed.
+__device__ __forceinline__ void own_add(const Sample3& ls, uint32_t slot, D3 add, bool& lit);
 struct ShadeOut {
     bool alive = false, shadow = false;  // the path continues / a shadow ray was made
     uint32_t slot = 0;
@@ -560,16 +561,19 @@ struct ShadeOut {
 struct PathRec {
     uint32_t slot;
     D3 T;
+    double prev_pdf;  // NEE: pdf of the BRDF sample that spawned the ray (the MIS weight of a hit on a light)
 };
-template <bool FIRST>
+template <bool FIRST, bool NEE>
 __device__ __forceinline__ PathRec load_rec(const Queue& in, uint32_t i) {
-    if (FIRST) return {i, mk(1., 1., 1.)};
-    return {in.slot[i], mk(in.T[0][i], in.T[1][i], in.T[2][i])};
+    if (FIRST) return {i, mk(1., 1., 1.), 0.};
+    return {in.slot[i], mk(in.T[0][i], in.T[1][i], in.T[2][i]), NEE ? in.prev_pdf[i] : 0.};
 }
 //   DIFFS = PT_FLAG_PROPAGATE_DIFFS (with USE_DIFFS, on a scene with textures): rays carry their
 //           differential rays through the queue (Queue::diff) and every vertex spawns them as the
 //           legacy reflect_diff / refract_diff do.
-template <bool FIRST, bool LAST, bool NEE, int MATS, bool FUSED, bool DIFFS = false>
+//   OWN   = the lane is the bounce-0 lane of its slot and has not stored the slot's bit of Sample3::lit yet
+//           (r.lit holds it): the second vertex of the kernel that traces bounces 0 and 1 in one go (k_path F01).
+template <bool FIRST, bool LAST, bool NEE, int MATS, bool FUSED, bool DIFFS = false, bool OWN = false>
 __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, uint32_t bounce, const Queue& in,
                                              uint32_t i, PathRec rec, uint32_t leaf, double t_hit, D3 o, D3 d,
                                              const Sample3& ls, ShadeOut& r) {
@@ -619,7 +623,7 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
             // bit for bit: negation commutes exactly with the cross product and the normalisation)
             double cos_l = leaf >= PT_PRIM_BASE ? dot(normal, -d) : fabs(dot(normal, d));
             double p_l = cos_l <= 0. ? 0. : t * t / (sc.light_area * cos_l);
-            double pp = in.prev_pdf[i];
+            double pp = rec.prev_pdf;
             double wgt = pp > 0. ? pp / (pp + p_l) : (pp < 0. ? 1. : 0.);  // pp < 0: specular predecessor
             add = T * le * wgt;
         }
@@ -792,10 +796,19 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
             double* c = ls.c + (size_t)slot * 3;
             c[0] = 0. + add.x; c[1] = 0. + add.y; c[2] = 0. + add.z;
             r.lit = true;
+        } else if (OWN) {  // radiance_add() with the slot's bit still in the register
+            own_add(ls, slot, add, r.lit);
         } else {
             radiance_add(ls, slot, add);
         }
     }
+}
+// color_result += add for the lane that owns the slot's bit (bounce 0, before store_lit): the arithmetic of
+// radiance_add (a first value is 0 + add, a later one is added), the bit kept in `lit`
+__device__ __forceinline__ void own_add(const Sample3& ls, uint32_t slot, D3 add, bool& lit) {
+    double* c = ls.c + (size_t)slot * 3;
+    if (lit) { c[0] += add.x; c[1] += add.y; c[2] += add.z; }
+    else { c[0] = 0. + add.x; c[1] = 0. + add.y; c[2] = 0. + add.z; lit = true; }
 }
 // bounce 0: the wave's 64 slots are one word of Sample3::lit (i0 = the wave's first slot, a multiple
 // of 64); called by all lanes of the wave, converged
@@ -843,7 +856,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
             ShadeOut r;
             uint32_t leaf = hits.tri[i];
             double t = (leaf != PT_MISS && NEE) ? hits.t[i] : 0.;
-            shade_vertex<FIRST, LAST, NEE, MATS, false, DIFFS>(sc, fr, bounce, in, i, load_rec<FIRST>(in, i), leaf, t,
+            shade_vertex<FIRST, LAST, NEE, MATS, false, DIFFS>(sc, fr, bounce, in, i, load_rec<FIRST, NEE>(in, i), leaf, t,
                                                                 mk(0., 0., 0.), mk(0., 0., 0.), ls, r);
         }
     }
@@ -858,7 +871,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
         uint32_t leaf = hits.tri[i];
         // the hit distance is only needed (and only loaded) where the vertex is shaded in full
         double t = (leaf != PT_MISS && (!LAST || NEE)) ? hits.t[i] : 0.;
-        shade_vertex<FIRST, LAST, NEE, MATS, false, DIFFS>(sc, fr, bounce, in, i, load_rec<FIRST>(in, i), leaf, t,
+        shade_vertex<FIRST, LAST, NEE, MATS, false, DIFFS>(sc, fr, bounce, in, i, load_rec<FIRST, NEE>(in, i), leaf, t,
                                                             mk(0., 0., 0.), mk(0., 0., 0.), ls, r);
     }
     if (FIRST) store_lit(ls, i - (threadIdx.x & 63u), n, r.lit);
@@ -895,7 +908,13 @@ template <int DEPTH, bool LDS = false> struct PathBlock {
 // the first live block (~6 KB, 48 B per thread) and every dependent fetch of the traversal becomes a
 // ds_read instead of a trip through the vector L1.
 constexpr int kMatWords = (int)(sizeof(Material) / sizeof(double));
-template <int DEPTH, bool FIRST, bool LAST, bool NEE, int MATS, bool LDS = false>
+// F01 = bounces 0 and 1 in one go (FIRST && !LAST && LDS, max_bounces >= 2): a lane whose path survives its first
+// vertex traces and shades the second one at once, in registers - no 76-byte record written and read back, no
+// compaction, no second copy of the scene into LDS, one launch and one tail instead of two.  Lanes whose path
+// ended at the first vertex idle meanwhile, so this is for scenes whose primary rays nearly all hit
+// (Scene::fuse01: CornellBox 97 %).  Same arithmetic per path, additions in the same order: same bits.
+// `mid_push` counts the paths that go on to the second vertex (the rays of bounce 1, for the statistics).
+template <int DEPTH, bool FIRST, bool LAST, bool NEE, int MATS, bool LDS = false, bool F01 = false>
 #ifndef PT_TEX_WAVES
 #define PT_TEX_WAVES 5
 #endif
@@ -905,7 +924,8 @@ template <int DEPTH, bool FIRST, bool LAST, bool NEE, int MATS, bool LDS = false
 // them too measured -0.4 ... -4 % on CornellBox and 0 on glossy_planes.
 __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), ((MATS & 1) ? PT_TEX_WAVES : 1)) void k_path(Scene gsc, Frame fr, uint32_t bounce, Queue in, Live live, Queue out,
                                                  Push out_push, ShadowQueue sq, Push sq_push, Sample3 ls,
-                                                 Counters* ctr) {
+                                                 Counters* ctr, Push mid_push) {
+    static_assert(!F01 || (FIRST && !LAST && LDS), "the two-bounce form is the primary launch of a scene in LDS");
     constexpr int kPathBlock = PathBlock<DEPTH, LDS>::value;
     __shared__ int stack[DEPTH * kPathBlock];
     __shared__ float4 s_top[(DEPTH > 8 && kTopNodes > 0) ? kTopNodes * 8 : 1];
@@ -920,7 +940,7 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), ((MATS & 1) ? PT_TE
     __shared__ double s_mats[LDS ? kLdsMats * kMatWords : 1];
     __shared__ float4 s_eye_nodes[(LDS && FIRST) ? kLdsScene * 4 : 1];
     __shared__ float4 s_eye_tris[(LDS && FIRST) ? kLdsScene * 7 : 1];
-    constexpr bool kEdges = LDS && (!FIRST || NEE);  // some ray of this kernel is traced by traverse()
+    constexpr bool kEdges = LDS && (!FIRST || NEE || F01);  // some ray of this kernel is traced by traverse()
     __shared__ float4 s_edges[kEdges ? kLdsScene * 7 : 1];
     static_assert(sizeof(TriShade) == 32 && sizeof(TriBasis) == 48 && sizeof(EyeNode) == 64 && sizeof(EyeTri) == 112 && sizeof(Material) % 8 == 0, "LDS copies");
     Scene sc = gsc;
@@ -941,6 +961,7 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), ((MATS & 1) ? PT_TE
         atomicAdd(&ctr->rays, FIRST ? (unsigned long long)fr.n_on_screen * fr.n_samples : live_total(live));
     ShadeOut r;
     r.n_o = r.n_d = r.n_T = r.s_d = r.s_c = mk(0., 0., 0.);
+    uint32_t n_mid = 0, n_shadow = 0;  // F01: this lane's path reached its second vertex; light samples it took
     const bool sparse = LAST && !FIRST && live.counts && live.sparse;
     for (uint32_t blk = blockIdx.x;; blk += gridDim.x) {  // one pass, except over a sparse queue
         uint32_t begin, end;
@@ -960,7 +981,7 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), ((MATS & 1) ? PT_TE
             const float4* g_shade = reinterpret_cast<const float4*>(gsc.tri_shade);
             const double* g_mats = reinterpret_cast<const double*>(gsc.mats);
             // (the primary bounce walks the eye tables; it needs the general arrays only for shadow rays and uvs)
-            constexpr bool kGeneral = !FIRST || NEE || (MATS & 1);
+            constexpr bool kGeneral = !FIRST || NEE || (MATS & 1) || F01;
             if (kGeneral) {
                 for (uint32_t k = threadIdx.x; k < gsc.n_nodes * 4; k += kPathBlock) s_nodes[k] = gsc.nodes[k];
                 for (uint32_t k = threadIdx.x; k < gsc.n_tris * 3; k += kPathBlock) s_tris[k] = gsc.tris[k];
@@ -1004,7 +1025,7 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), ((MATS & 1) ? PT_TE
                 o = mk(in.o[0][i], in.o[1][i], in.o[2][i]);
                 d = mk(in.d[0][i], in.d[1][i], in.d[2][i]);
             }
-            const PathRec rec = load_rec<FIRST>(in, i);  // in flight while the tree is walked
+            const PathRec rec = load_rec<FIRST, NEE>(in, i);  // in flight while the tree is walked
             double t = 1.7976931348623157e308;  // ray.rs:22 f64::MAX; t_min = 1e-5 (ray.rs:21)
             uint32_t nn = 0, nt = 0;
             uint32_t leaf = PT_MISS;
@@ -1012,20 +1033,30 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), ((MATS & 1) ? PT_TE
                 leaf = (FIRST && (LDS || sc.eye_nodes)) ? traverse_eye<DEPTH, kPathBlock>(sc, d, 1e-5, t, stack + threadIdx.x)
                                                : traverse<DEPTH, false, false, kPathBlock, LDS>(sc, o, d, 1e-5, t, stack + threadIdx.x, nn, nt, top);
             shade_vertex<FIRST, LAST, NEE, MATS, true>(sc, fr, bounce, in, i, rec, leaf, t, o, d, ls, r);
-            if (NEE && !LAST && sc.fuse_shadow && r.shadow) {
-                // the light sample's visibility, in place: the shadow ray never leaves the registers
-                // (84 B written + read per shadow ray and one launch per bounce otherwise).  Same order
-                // of additions as the shadow kernel's: the vertex's emission first, then its light sample.
+            // the light sample's visibility, in place: the shadow ray never leaves the registers
+            // (84 B written + read per shadow ray and one launch per bounce otherwise).  Same order
+            // of additions as the shadow kernel's: the vertex's emission first, then its light sample.
+            auto trace_shadow = [&](bool own) {
                 double st_max = r.s_tmax;
                 uint32_t nn2 = 0, nt2 = 0;
                 if (traverse<DEPTH, true, false, kPathBlock, LDS>(sc, r.n_o, r.s_d, 1e-5, st_max, stack + threadIdx.x, nn2, nt2, top) == PT_MISS) {
-                    if (FIRST) {
-                        double* c = ls.c + (size_t)r.slot * 3;
-                        if (r.lit) { c[0] += r.s_c.x; c[1] += r.s_c.y; c[2] += r.s_c.z; }
-                        else { c[0] = 0. + r.s_c.x; c[1] = 0. + r.s_c.y; c[2] = 0. + r.s_c.z; r.lit = true; }
-                    } else {
-                        radiance_add(ls, r.slot, r.s_c);
-                    }
+                    if (own) own_add(ls, r.slot, r.s_c, r.lit);
+                    else radiance_add(ls, r.slot, r.s_c);
+                }
+            };
+            if (NEE && !LAST && sc.fuse_shadow && r.shadow) trace_shadow(FIRST);
+            if (F01) {
+                n_shadow += r.shadow;
+                if (r.alive) {  // the second vertex of the path, at once
+                    const D3 o2 = r.n_o, d2 = r.n_d;
+                    const PathRec rec2{r.slot, r.n_T, r.n_pdf};
+                    r.alive = false; r.shadow = false;
+                    n_mid = 1;
+                    double t2 = 1.7976931348623157e308;
+                    const uint32_t leaf2 = traverse<DEPTH, false, false, kPathBlock, LDS>(sc, o2, d2, 1e-5, t2, stack + threadIdx.x, nn, nt, top);
+                    shade_vertex<false, false, NEE, MATS, true, false, true>(sc, fr, bounce + 1, in, i, rec2, leaf2, t2, o2, d2, ls, r);
+                    if (NEE && r.shadow) trace_shadow(true);
+                    n_shadow += r.shadow;
                 }
             }
         }
@@ -1037,6 +1068,19 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), ((MATS & 1) ? PT_TE
     uint32_t pos = region * out_push.seg_size + (kPathBlock == 64 ? compact_wave(r.alive, out_push.counts + region * kCtrStride)
                                                                    : compact_slot<kPathBlock>(r.alive, out_push.counts + region * kCtrStride, lds_a));
     if (r.alive) push_path<NEE>(out, pos, r);
+    if (F01) {
+        // statistics only: the rays of bounce 1 and the light samples of both vertices, one atomic per wave each
+        // (the counters of the queues this launch does not fill)
+        const uint32_t mid = (uint32_t)__popcll(__ballot(n_mid != 0));
+        uint32_t sh = n_shadow;
+#pragma unroll
+        for (int d = 32; d; d >>= 1) sh += __shfl_down(sh, d);
+        if ((threadIdx.x & 63u) == 0) {
+            if (mid) atomicAdd(mid_push.counts + region * kCtrStride, mid);
+            if (NEE && sh) atomicAdd(sq_push.counts + region * kCtrStride, sh);
+        }
+        return;
+    }
     if (NEE) {
         // (fuse_shadow: only the count is kept, for the statistics)
         uint32_t spos = region * sq_push.seg_size + (kPathBlock == 64 ? compact_wave(r.shadow, sq_push.counts + region * kCtrStride)

@@ -277,6 +277,7 @@ def test_scene_options_select_the_same_variants_as_the_environment(gpu, monkeypa
         (dict(fuse_shadow=0), dict(PT_FUSE_SHADOW="0")),
         (dict(vote_primary=1, vote_secondary=1, vote_shadow=1, wave_rays=128), FORCE_VOTE),
         (dict(lds_scene=0), dict(PT_LDS_SCENE="0")),
+        (dict(fuse01=0), dict(PT_FUSE01="0")),
         (dict(eye_tables=0), dict(PT_EYE_TABLES="0")),
         (dict(light_cull=0, screen_cull=0, persistent=0), dict(PT_LIGHT_CULL="0", PT_SCREEN_CULL="0", PT_PERSISTENT="0")),
         (dict(pipeline=1, bvh_max_leaf=4, bvh_threads=2), dict(PT_PIPELINE="1", PT_BVH_LEAF="4", PT_BVH_THREADS="2")),
@@ -453,6 +454,62 @@ def test_fused_path_kernel_is_bitwise_identical(gpu, monkeypatch, name):
             cfg = pt.Config(width=83, height=47, samples_pr_pixel=3, bounces=bounces, seed=12, nee=nee, drop_nonfinite=True)
             a, b = plain.render(cfg), fused.render(cfg)
             assert a.tobytes() == b.tobytes(), (name, nee, bounces)
+
+
+@pytest.mark.parametrize("name", ["CornellBox", "Test", "glossy_planes", "tilted_mirror", "sparse_hits"])
+def test_two_bounce_kernel_is_bitwise_identical(gpu, name):
+    # k_path F01: the primary launch of a scene that lives in LDS traces and shades the path's second vertex too
+    # (no record written and read back between bounces 0 and 1) against one launch per bounce: same arithmetic per
+    # path, additions in the same order, so the same bytes - textures, Glossy with NaN-producing samples, NEE with
+    # its in-kernel shadow rays, Russian roulette, more bounces than two, tiles, a row partition, odd sizes; and the
+    # ray statistics agree.  With fewer than two bounces the kernel does not apply and the paths coincide.
+    if name == "tilted_mirror":
+        from pathtracer_amd.synthetic import tilted_mirror
+        data = tilted_mirror()
+    elif name == "sparse_hits":      # most primary rays miss: the probe leaves the kernel off, the option forces it
+        import copy
+        data = copy.copy(pt.scene_data("CornellBox"))
+        c = data.camera
+        data.camera = pt.Camera((0.5, 0.5, -6.0), c.view_direction, c.up_direction, 1.0)
+        data.background = (0.05, 0.1, 0.2)
+    else:
+        data = pt.scene_data(name, textures=name == "Test", specular=name == "Test")
+    one = pt.Scene(data, gpu, options=dict(fuse01=0))
+    two = pt.Scene(data, gpu, options=dict(fuse01=1))
+    auto = pt.Scene(data, gpu, options={})
+    cfgs = [pt.Config(width=83, height=47, samples_pr_pixel=3, bounces=b, seed=12, nee=nee)
+            for nee in (False, True) for b in (0, 1, 2, 4)]
+    cfgs += [pt.Config(dim=64, samples_pr_pixel=2, bounces=6, seed=9, nee=True, russian_roulette=True),
+             pt.Config(dim=256, samples_pr_pixel=64, seed=1, bounces=2)]
+    for cfg in cfgs:
+        one.reset_stats(); two.reset_stats()
+        a, b = one.render(cfg), two.render(cfg)
+        assert a.tobytes() == b.tobytes(), (name, cfg)
+        sa, sb = one.stats(), two.stats()
+        assert (sa["rays"], sa["shadow_rays"], sa["samples"]) == (sb["rays"], sb["shadow_rays"], sb["samples"]), (name, cfg)
+        assert auto.render(cfg).tobytes() == a.tobytes()
+    cfg = pt.Config(width=211, height=97, samples_pr_pixel=5, bounces=3, seed=4, nee=True, spp_per_batch=2)
+    whole = one.render(cfg)
+    acc = np.zeros_like(whole)
+    for x0, x1 in ((0, 70), (70, 211)):
+        two.render(cfg, acc, tile=(x0, 0, x1, 97))
+    assert acc.tobytes() == whole.tobytes()
+    acc = np.zeros_like(whole)
+    for index in range(3):
+        two.render(cfg, acc, rows=(8, 3, index))
+    assert acc.tobytes() == whole.tobytes()
+    if name == "tilted_mirror":
+        assert not np.isfinite(one.render(cfgs[-1])).all()       # the NaN pixels are there, on both paths alike
+    # the launch counts tell which path ran
+    for sc, want in ((one, 3), (two, 2)):
+        sc.reset_stats(); sc.set_profiling(1)
+        sc.render(pt.Config(dim=64, samples_pr_pixel=2, bounces=2, seed=1))
+        assert sc.stats()["kernel"]["path"]["launches"] == want
+        sc.set_profiling(0)
+    auto.reset_stats(); auto.set_profiling(1)
+    auto.render(pt.Config(dim=64, samples_pr_pixel=2, bounces=2, seed=1))
+    assert auto.stats()["kernel"]["path"]["launches"] == (3 if name in ("sparse_hits", "tilted_mirror") else 2)   # the probe
+    auto.set_profiling(0)
 
 
 def test_baseline_full_size_cornellbox_1080p(scenes):

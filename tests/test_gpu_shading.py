@@ -265,8 +265,16 @@ def test_stats_counters(trio):
     st1 = scene.stats()
     scene.set_profiling(0)
     k = st1["kernel"]
-    assert k["path"]["launches"] == 3 and k["extend"]["launches"] == 0 and k["shade"]["launches"] == 0
+    # ... and, the scene living in LDS, bounces 0 and 1 in ONE launch (k_path F01), then the sparse last bounce
+    assert k["path"]["launches"] == 2 and k["extend"]["launches"] == 0 and k["shade"]["launches"] == 0
     assert st1["rays"] == st["rays"]
+    # fuse01 = 0: one launch per bounce; same rays, same image
+    plain = pt.Scene(data, device=scene.device, options={"fuse01": 0})
+    plain.set_profiling(1)
+    img_plain = plain.render(cfg)
+    st2 = plain.stats()
+    assert st2["kernel"]["path"]["launches"] == 3 and st2["rays"] == st["rays"]
+    assert img_plain.tobytes() == scene.render(cfg).tobytes()
 
 
 def test_progressive_checkpoint_resume_is_bit_identical(trio, tmp_path):
