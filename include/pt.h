@@ -268,13 +268,15 @@ typedef struct pt_scene_options {
                               * LDS by every traversal wave (default on) */
     int8_t fuse01;           /* a scene that lives in LDS: the primary launch traces the path's second vertex too
                               * (default: on when a probe of the primary rays finds that at least half of them hit) */
-    int8_t reserved8[2];     /* 0 */
+    int8_t packet_primary;   /* deep trees: the 64 primary rays of a wave walk the four-wide tree together (one node
+                              * index, one stack, per wave; default on) instead of one traversal per lane */
+    int8_t reserved8[1];     /* 0 */
 } pt_scene_options;
 /* every field to its default */
 void pt_scene_options_init(pt_scene_options* options);
 /* ... then the overrides of the process environment, for tuning sweeps without a rebuild: PT_TRAV_VOTE_PRIMARY,
  * PT_TRAV_VOTE, PT_TRAV_VOTE_SHADOW, PT_FUSE, PT_FUSE_SHADOW, PT_LIGHT_CULL, PT_SCREEN_CULL, PT_PIPELINE,
- * PT_PERSISTENT, PT_EYE_TABLES, PT_LDS_SCENE, PT_LDS_TOP, PT_FUSE01 = 0|1; PT_GROUP_FRAMES = 0..6; PT_WAVE_RAYS, PT_BVH_LEAF, PT_BVH_THREADS = counts.  This is the
+ * PT_PERSISTENT, PT_EYE_TABLES, PT_LDS_SCENE, PT_LDS_TOP, PT_FUSE01, PT_PACKET = 0|1; PT_GROUP_FRAMES = 0..6; PT_WAVE_RAYS, PT_BVH_LEAF, PT_BVH_THREADS = counts.  This is the
  * only function of the library that reads the environment. */
 void pt_scene_options_from_env(pt_scene_options* options);
 

@@ -71,7 +71,7 @@ class pt_scene_options(C.Structure):
         "vote_primary", "vote_secondary", "vote_shadow", "fuse", "fuse_shadow", "light_cull", "screen_cull", "pipeline",
         "persistent", "eye_tables", "lds_scene", "group_frames")] + [
         ("wave_rays", C.c_uint32), ("bvh_max_leaf", C.c_uint32), ("bvh_threads", C.c_uint32),
-        ("lds_top", C.c_int8), ("fuse01", C.c_int8), ("reserved8", C.c_int8 * 2)]
+        ("lds_top", C.c_int8), ("fuse01", C.c_int8), ("packet_primary", C.c_int8), ("reserved8", C.c_int8 * 1)]
 
 
 class pt_ray(C.Structure):

@@ -148,6 +148,8 @@ struct Scene {
     uint8_t lds_scene;  // the scene is small enough to live in LDS inside the fused kernel (k_path LDS)
     uint32_t n_mats;
     uint8_t fuse_shadow;  // ... and the bounce's light sample traced in that kernel too
+    uint8_t packet_primary;  // deep trees: the primary rays of a wave walk the four-wide tree together (traverse_packet4) where the
+                             // wave holds at most 64 >> packet_primary pixels (Frame::grp_log2 >= packet_primary); 0 = never
     uint8_t fuse01;       // ... and the primary launch of a scene in LDS takes the path's second vertex along (k_path F01)
     uint32_t wave_rays;
     uint32_t n_cu;  // compute units of the device (size of a persistent launch)

@@ -533,6 +533,90 @@ __device__ __forceinline__ uint32_t traverse(const Scene& sc, D3 o, D3 d, double
     return best;
 }
 
+// ---- packet traversal of the four-wide tree: the 64 rays of a wave walk the tree TOGETHER ------------------------
+// For waves whose rays are coherent - the primary rays of a deep tree, where a wave holds one pixel in 64 frames
+// (Frame::grp_log2) and its rays differ by the frame jitter alone.  The node index, the stack and the visiting
+// order are wave-uniform (scalar registers, one LDS column): a node is opened if ANY lane's slab test passes, a
+// leaf's triangles are tested by every lane.  Against one traversal per lane there is no per-lane stack traffic, no
+// per-lane sorting network, no divergence between lanes that are at different depths, and a node is fetched once
+// per wave, through one address.  Each lane still runs the same slab tests against its own ray and the same f64
+// triangle tests with its own t_max, and a superset of the leaves it would have opened alone is opened, so its
+// closest hit (and the lowest-id tie rule) is what traverse() finds: ids and distances are bit-identical (tested).
+// `ustk`: kWideStack ints of LDS for the wave.  Lanes with active == false hit nothing.
+template <bool STATS>
+__device__ __forceinline__ uint32_t traverse_packet4(const Scene& sc, D3 o, D3 d, double t_min, double& t_max, bool active,
+                                                     int* ustk, TopNodes top, uint32_t& n_nodes, uint32_t& n_tris) {
+    uint32_t best = PT_MISS, best_id = PT_MISS;
+    if (sc.n_prims && active) prims_closest(sc, o, d, t_min, t_max, best, best_id);
+    if (sc.n_nodes == 0 || !__ballot(active)) return best;
+    const RayF rf = make_rayf(o, d);
+    const float t_min32 = f32_down(t_min);
+    float t_max32 = active ? f32_up(t_max) : -1.f;   // below t_min: every slab test fails
+    int sp = 0, cur = 0;                              // wave-uniform
+    for (;;) {
+        while (cur >= 0) {
+            float4 lx, ly, lz, hx, hy, hz, cf;
+            if (kTopNodes > 0 && cur < top.n) {
+                LdsF4 np = top.p + cur * 8;
+                lx = ldsf4(np, 0); ly = ldsf4(np, 1); lz = ldsf4(np, 2); hx = ldsf4(np, 3); hy = ldsf4(np, 4); hz = ldsf4(np, 5); cf = ldsf4(np, 6);
+            } else {
+                const float4* np = sc.nodes4 + (size_t)cur * 8;
+                lx = np[0]; ly = np[1]; lz = np[2]; hx = np[3]; hy = np[4]; hz = np[5]; cf = np[6];
+            }
+            const int c[4] = {__float_as_int(cf.x), __float_as_int(cf.y), __float_as_int(cf.z), __float_as_int(cf.w)};
+            const float lox[4] = {lx.x, lx.y, lx.z, lx.w}, loy[4] = {ly.x, ly.y, ly.z, ly.w}, loz[4] = {lz.x, lz.y, lz.z, lz.w};
+            const float hix[4] = {hx.x, hx.y, hx.z, hx.w}, hiy[4] = {hy.x, hy.y, hy.z, hy.w}, hiz[4] = {hz.x, hz.y, hz.z, hz.w};
+            uint32_t key[4];
+            int ch[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float tn;
+                const bool hit = slab32(lox[k], loy[k], loz[k], hix[k], hiy[k], hiz[k], rf, t_min32, t_max32, tn);
+                if (STATS) n_nodes += active && c[k] != PT_BVH_EMPTY;
+                const unsigned long long m = __ballot(hit);
+                ch[k] = __builtin_amdgcn_readfirstlane(c[k]);
+                // the child is opened if any lane hits its box; visiting order by the entry distance of the first such lane
+                const bool any = m != 0 && ch[k] != PT_BVH_EMPTY;
+                const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tn), any ? (int)__builtin_ctzll(m) : 0);
+                key[k] = any ? lead : 0xFFFFFFFFu;
+            }
+#define PT_CSWAP(a, b) { const bool sw_ = key[b] < key[a]; \
+        const uint32_t ka_ = sw_ ? key[b] : key[a], kb_ = sw_ ? key[a] : key[b]; \
+        const int ca_ = sw_ ? ch[b] : ch[a], cb_ = sw_ ? ch[a] : ch[b]; \
+        key[a] = ka_; key[b] = kb_; ch[a] = ca_; ch[b] = cb_; }
+            PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
+#undef PT_CSWAP
+            if (key[0] == 0xFFFFFFFFu) {
+                if (sp == 0) { cur = kDone; break; }
+                cur = __builtin_amdgcn_readfirstlane(ustk[--sp]);
+                continue;
+            }
+            // (the collapse bounds the pending subtrees of ANY root-to-leaf walk by kWideStack, whichever children are opened)
+            if (key[3] != 0xFFFFFFFFu) { PT_STACK_CHECK(sp, kWideStack); ustk[sp++] = ch[3]; }
+            if (key[2] != 0xFFFFFFFFu) { PT_STACK_CHECK(sp, kWideStack); ustk[sp++] = ch[2]; }
+            if (key[1] != 0xFFFFFFFFu) { PT_STACK_CHECK(sp, kWideStack); ustk[sp++] = ch[1]; }
+            cur = ch[0];
+        }
+        if (cur == kDone) break;
+        const uint32_t code = (uint32_t)~cur, first = code >> 3, cnt = (code & 7u) + 1u;   // uniform
+        for (uint32_t k = 0; k < cnt; ++k) {
+            const float4* tp = sc.tris + (size_t)(first + k) * 3;
+            const float4 a = tp[0], b = tp[1], c = tp[2];
+            const TriV tr = widen(a, b, c);
+            if (STATS) n_tris += active;
+            double t, v, w;
+            if (!active || !tri_test(tr, o, d, t_min, t_max, t, v, w)) continue;
+            const uint32_t gid = (uint32_t)__float_as_int(a.w);
+            if (best != PT_MISS && !(t < t_max || gid < best_id)) continue;   // lowest id wins a tie, as in traverse()
+            best = first + k; best_id = gid; t_max = t;
+            t_max32 = f32_up(t);
+        }
+        if (sp == 0) break;
+        cur = __builtin_amdgcn_readfirstlane(ustk[--sp]);
+    }
+    return best;
+}
+
 // ---- primary rays of a small scene: the eye-relative tables (pt_device.h EyeNode / EyeTri) -----
 // slab32 with the subtraction done once per scene: r = (lo - o - E, hi - o + E) rounded outward to f32 by
 // k_build_eye_tables (directed, so only the reciprocal's 3 u and the product's rounding remain: 4 u |r| of

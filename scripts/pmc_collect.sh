@@ -14,9 +14,10 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
            "SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_RD SQ_LDS_BANK_CONFLICT" \
            "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_MUL_F32" \
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" \
-           "FETCH_SIZE" "WRITE_SIZE" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_BUSY_avr GRBM_GUI_ACTIVE"; do
+           "FETCH_SIZE" "WRITE_SIZE" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_BUSY_avr GRBM_GUI_ACTIVE" \
+           "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM_WR SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE"; do
   i=$((i+1))
-  timeout -s KILL 240 rocprofv3 --pmc $grp -d $OUT/p$i -o p --output-format csv -- python3 $ROOT/bench.py --configs none --cpu-seconds 0 --no-roofline "$@" > $OUT/p$i.log 2>&1
+  timeout -s KILL 240 rocprofv3 --pmc $grp -d $OUT/p$i -o p --output-format csv -- python3 $ROOT/bench.py --configs none --cpu-seconds 0 --no-cull-steps 0 --no-roofline "$@" > $OUT/p$i.log 2>&1
   rc=$?
   echo "pass $i ($grp) rc=$rc"
   if [ $rc -ne 0 ]; then tail -3 $OUT/p$i.log; exit $rc; fi

@@ -81,6 +81,20 @@ def main():
             lane = d.get("lane_utilisation") or 1.0
             # flops actually done: wave instructions x 64 lanes x the share of lanes that are on (FMA = 2)
             d["fp64_flops_per_launch"] = round((f64["ADD_F64"] + f64["MUL_F64"] + f64["TRANS_F64"] + 2.0 * f64["FMA_F64"]) * 64.0 * lane)
+        if per("SQ_INSTS_VALU") and any(f64.values()):
+            # instruction mix per wave: what the vector issue slots are spent on.  Classified by the SQ counters; the
+            # remainder ("other") is what no counter names: moves, selects, compares, min / max, bit operations, lane ops
+            w = max(per("SQ_WAVES"), 1.0)
+            mix = {
+                "f64_arith": (f64["ADD_F64"] + f64["MUL_F64"] + f64["FMA_F64"] + f64["TRANS_F64"]) / w,
+                "f32_arith": sum(per("SQ_INSTS_VALU_" + k) for k in ("ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32")) / w,
+                "int32": per("SQ_INSTS_VALU_INT32") / w, "int64": per("SQ_INSTS_VALU_INT64") / w, "cvt": per("SQ_INSTS_VALU_CVT") / w,
+            }
+            mix["other_valu"] = per("SQ_INSTS_VALU") / w - sum(mix.values())
+            d["valu_mix_per_wave"] = {k: round(v, 1) for k, v in mix.items()}
+            d["valu_mix_share"] = {k: round(v * w / per("SQ_INSTS_VALU"), 3) for k, v in mix.items()}
+            d["non_valu_per_wave"] = {k.lower(): round(per("SQ_INSTS_" + k) / w, 1) for k in
+                                      ("SALU", "SMEM", "BRANCH", "LDS", "LDS_LOAD", "LDS_STORE", "VMEM_RD", "VMEM_WR") if per("SQ_INSTS_" + k)}
         hit, miss = t.get("TCC_HIT_sum", 0.0), t.get("TCC_MISS_sum", 0.0)
         if hit + miss:
             d["l2_hit"] = round(hit / (hit + miss), 3)

@@ -12,7 +12,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 "$ROOT/scripts/pmc_collect.sh" "$TAG" "${PMC_ARGS[@]}" || exit $?
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d "$ROOT/gpurun_out/kt_$TAG" -o kt --output-format csv -- \
-    python3 "$ROOT/bench.py" --configs none --cpu-seconds 0 "$@" > "$ROOT/gpurun_out/kt_$TAG.json" 2> "$ROOT/gpurun_out/kt_$TAG.err"
+    python3 "$ROOT/bench.py" --configs none --cpu-seconds 0 --no-cull-steps 0 "$@" > "$ROOT/gpurun_out/kt_$TAG.json" 2> "$ROOT/gpurun_out/kt_$TAG.err"
 rc=$?
 echo "kernel trace rc=$rc"; tail -c 600 "$ROOT/gpurun_out/kt_$TAG.json"
 exit $rc

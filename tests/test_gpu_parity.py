@@ -512,6 +512,33 @@ def test_two_bounce_kernel_is_bitwise_identical(gpu, name):
     auto.set_profiling(0)
 
 
+@pytest.mark.parametrize("cells", [40, 300])
+def test_packet_traversal_of_primary_rays_is_bitwise_identical(gpu, cells):
+    # deep trees: the 64 primary rays of a wave walk the four-wide tree together (traverse_packet4: wave-uniform node
+    # index and stack, a node opened if any lane hits its box) against one traversal per lane: every lane runs the
+    # same slab and triangle tests on a superset of the leaves, so hit ids / distances and the image are the same
+    # bits - frame counts that put one pixel in 64 frames per wave, a few pixels per wave, an 8x8 block per wave;
+    # off-screen lanes, partial waves, NEE, a row partition, the top of the tree in LDS or not.
+    from pathtracer_amd.synthetic import heightfield_box
+    data = heightfield_box(cells=cells)
+    lane = pt.Scene(data, gpu, options=dict(packet_primary=0))
+    for extra in ({}, dict(lds_top=0), dict(group_frames=0), dict(group_frames=3)):
+        packet = pt.Scene(data, gpu, options=dict(packet_primary=1, **extra))
+        for cfg in (pt.Config(width=211, height=97, samples_pr_pixel=64, bounces=2, seed=3, spp_per_batch=64),
+                    pt.Config(width=160, height=90, samples_pr_pixel=5, bounces=2, seed=4, nee=True),
+                    pt.Config(dim=96, samples_pr_pixel=128, bounces=0, seed=5)):
+            lane.reset_stats(); packet.reset_stats()
+            a, b = lane.render(cfg), packet.render(cfg)
+            assert a.any() and a.tobytes() == b.tobytes(), (cells, extra, cfg)
+            assert lane.stats()["rays"] == packet.stats()["rays"]
+        cfg = pt.Config(width=211, height=97, samples_pr_pixel=8, bounces=1, seed=6)
+        whole = lane.render(cfg)
+        acc = np.zeros_like(whole)
+        for index in range(3):
+            packet.render(cfg, acc, rows=(8, 3, index))
+        assert acc.tobytes() == whole.tobytes()
+
+
 def test_baseline_full_size_cornellbox_1080p(scenes):
     # BASELINE.json configs[1] geometry at its full image size: primary hits bit-exact against the
     # oracle on all 2,073,600 rays, and the size-independent properties of the accumulation
