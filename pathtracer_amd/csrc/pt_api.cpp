@@ -125,6 +125,7 @@ void carve_workspace(Workspace& w, void* base, uint32_t n_slots, uint32_t lane_s
             ln.q[k].slot = c.take<uint32_t>(slots);
             ln.q[k].diff = diffs ? c.take<double>((size_t)12 * slots) : nullptr;
             ln.q[k].diff_stride = slots;
+            ln.q[k].stride9 = (uint32_t)((((size_t)slots * sizeof(double) + 255) & ~(size_t)255) / sizeof(double));  // Carver::take
         }
         ln.hits.tri = c.take<uint32_t>(slots);
         ln.hits.t = c.take<double>(slots);

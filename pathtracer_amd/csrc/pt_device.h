@@ -179,6 +179,10 @@ struct Queue {
     // diff_stride doubles: rx_origin, ry_origin, rx_direction, ry_direction (ray.rs:9-12)
     double* diff;
     uint32_t diff_stride;
+    // o[0..2], d[0..2], T[0..2] lie `stride9` doubles apart, in this order, from o[0] (carve_workspace); 0 = they do
+    // not (the staging of pt_trace_closest).  A kernel that appends through o[0] + k * stride9 keeps 3 scalar
+    // registers live for the queue instead of 18: the fused kernels spill scalar registers to vector lanes.
+    uint32_t stride9;
 };
 
 // Per-slot radiance of the batch ("color_result", main.rs:287).  Most samples of a frame gather no

@@ -826,9 +826,13 @@ __device__ __forceinline__ void push_path(const Queue& out, uint32_t pos, const 
 #pragma unroll
         for (int k = 0; k < 4; ++k) { q[3 * k * st] = v[k].x; q[(3 * k + 1) * st] = v[k].y; q[(3 * k + 2) * st] = v[k].z; }
     }
-    out.o[0][pos] = r.n_o.x; out.o[1][pos] = r.n_o.y; out.o[2][pos] = r.n_o.z;
-    out.d[0][pos] = r.n_d.x; out.d[1][pos] = r.n_d.y; out.d[2][pos] = r.n_d.z;
-    out.T[0][pos] = r.n_T.x; out.T[1][pos] = r.n_T.y; out.T[2][pos] = r.n_T.z;
+    {   // the nine arrays through one base pointer (Queue::stride9: every queue a kernel appends to is a carved one)
+        double* b = out.o[0] + pos;
+        const size_t st = out.stride9;
+        b[0] = r.n_o.x; b[st] = r.n_o.y; b[2 * st] = r.n_o.z;
+        b[3 * st] = r.n_d.x; b[4 * st] = r.n_d.y; b[5 * st] = r.n_d.z;
+        b[6 * st] = r.n_T.x; b[7 * st] = r.n_T.y; b[8 * st] = r.n_T.z;
+    }
     out.slot[pos] = r.slot;
     if (NEE) out.prev_pdf[pos] = r.n_pdf;
 }
