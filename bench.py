@@ -237,11 +237,16 @@ class Workload:
                 hbm["basis"] = "counter traffic: the caches serve part of the algorithmic bytes (algorithmic_GBs, algorithmic_frac)"
         valu = None
         if pmc.get("valu_busy_cycles_per_launch"):
-            # VALU issue: SIMD-cycles in which a vector instruction issues (SQ_ACTIVE_INST_VALU x 4, a count
-            # fixed by the workload: the RNG is counter-based) over the live launch duration, against
-            # 1024 SIMDs x the 2.4 GHz maximum clock.  lane_utilisation = active lanes per issued
-            # instruction / 64 (SQ_THREAD_CYCLES_VALU); useful = the two multiplied.
-            cyc = pmc["valu_busy_cycles_per_launch"]
+            # VALU issue against 1024 SIMDs x the 2.4 GHz maximum clock (counts fixed by the workload: the RNG is
+            # counter-based).  lane_utilisation = active lanes per issued instruction / 64
+            # (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU); useful = the two multiplied.
+            # achieved = vector instructions issued per launch (SQ_INSTS_VALU, a count fixed by the workload) x the 4
+            # cycles a wave64 instruction occupies a 16-lane SIMD, over the live launch duration.  The busy-cycle
+            # figure beside it (SQ_ACTIVE_INST_VALU x 4: per-wave cycles with a vector instruction in flight, which
+            # weighs quarter-rate f64 rcp / sqrt fully but overlaps between waves by the pipeline's depth, so it can
+            # pass 1) brackets the same thing from the other side.
+            cyc = pmc.get("valu_insts_per_launch", 0) * 4.0
+            busy = pmc["valu_busy_cycles_per_launch"]
             ach = cyc / (avg_ms * 1e-3) / 1e9
             peak = N_SIMD * MAX_CLOCK_HZ / 1e9
             lane = pmc.get("lane_utilisation")
@@ -249,8 +254,10 @@ class Workload:
             valu = {
                 "bound": "valu-issue", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G SIMD-cycles/s",
                 "frac": round(ach / peak, 4), "traffic": pmc.get("traffic_bytes_per_launch"),
+                "basis": "vector instructions issued x 4 cycles per wave64 instruction, over 1024 SIMDs x 2.4 GHz",
+                "busy_cycles_frac": round(busy / (avg_ms * 1e-3) / 1e9 / peak, 4),
                 "valu_busy_at_effective_clock": pmc.get("valu_busy"), "effective_clock_ghz": pmc.get("clock_ghz"),
-                "lane_utilisation": lane, "useful_lane_frac": round(ach / peak * lane, 4) if lane else None,
+                "lane_utilisation": lane, "useful_lane_frac": round(min(1.0, ach / peak) * lane, 4) if lane else None,
                 "valu_insts_per_launch": pmc.get("valu_insts_per_launch"),
                 "fp64_tflops": round(flops / (avg_ms * 1e-3) / 1e12, 2) if flops else None,
                 "fp64_peak_tflops_no_fma": FP64_VALU_PEAK_TFLOPS / 2,
