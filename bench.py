@@ -170,7 +170,9 @@ class Workload:
         #   shade       per ray 12 read; secondary ray: +76 read; per continuing path 76 written;
         #               per sample 1 bit, per sample that gathered radiance 24 written
         #   path        (extend+shade fused) secondary ray: 76 read; continuing path: 76 written;
-        #               per sample 1 bit, per lit sample 24 written
+        #               per sample 1 bit, per lit sample 24 written.  Where bounces 0 and 1 run in one launch
+        #               (pt_stats.two_bounce) the rays of bounce 1 never exist as records: only the rays of
+        #               bounce >= 2 are written and read
         #   accumulate  per sample 1 bit, per lit sample 24 read, per pixel and launch 48 (accum
         #               read-modify-write)
         # The scene terms 32 V + 36 T are HBM bytes of the traversing kernel only when the scene does
@@ -183,11 +185,13 @@ class Workload:
         lit = P * st2["lit_samples"] / max(1, st2["samples"])   # samples that gathered radiance
         P_traced = P * st0["rays"] / max(1, st0["samples"])     # primary rays actually traced (screen bounds)
         S = max(0.0, float(st["rays"]) - P_traced)  # secondary rays == records written
+        # ... minus the rays of bounce 1 where bounces 0 and 1 run in one launch: they stay in registers (pt_stats.unqueued_rays)
+        S_rec = max(0.0, S - float(st.get("unqueued_rays", 0)))
         scene_all = float(st["rays"]) * scene_ray
         per_kind = {
             "extend": P * hit + S * (48.0 + hit),
             "shade": (P + S) * hit + S * rec + S * rec + P / 8.0 + lit * 24.0,
-            "path": S * rec + S * rec + P / 8.0 + lit * 24.0,
+            "path": S_rec * rec + S_rec * rec + P / 8.0 + lit * 24.0,
             "accumulate": P / 8.0 + lit * 24.0 + float(npix) * 48.0 * max(1, kern["accumulate"]["launches"]),
             "shadow": float(st["shadow_rays"]) * (56.0 + 24.0 + 4.0),
             "generate": 0.0,

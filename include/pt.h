@@ -236,6 +236,11 @@ typedef struct pt_stats {
     uint64_t scene_bytes;    /* device bytes of the tree and the triangles the traversal reads */
     uint32_t tree_width;     /* children per node of the device tree: 2 (depth <= 8) or 4 (deeper: collapsed) */
     uint32_t stack_need;     /* traversal stack entries the deepest path of the device tree needs */
+    uint32_t two_bounce;     /* 1: renders of this scene with max_bounces >= 2 trace bounces 0 and 1 in one launch, so
+                              * no path record exists between them (pt_scene_options::fuse01) */
+    uint32_t packet_primary; /* 1: primary waves of this scene's deep tree walk it as packets where fully grouped */
+    uint64_t unqueued_rays;  /* of `rays`, the secondary rays that never existed as a 76-byte path record: the rays of
+                              * bounce 1 where bounces 0 and 1 run in one launch */
 } pt_stats;
 
 typedef struct pt_scene pt_scene;

@@ -99,7 +99,8 @@ class pt_stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
                 ("kernel", pt_kernel_stat * PT_K_COUNT), ("lit_samples", C.c_uint64),
-                ("scene_bytes", C.c_uint64), ("tree_width", C.c_uint32), ("stack_need", C.c_uint32)]
+                ("scene_bytes", C.c_uint64), ("tree_width", C.c_uint32), ("stack_need", C.c_uint32),
+                ("two_bounce", C.c_uint32), ("packet_primary", C.c_uint32), ("unqueued_rays", C.c_uint64)]
 
 
 # every symbol include/pt.h declares: name -> (restype, argtypes)

@@ -876,9 +876,12 @@ int pt_get_stats(pt_scene* s, pt_stats* out) {
     s->stats.nodes_visited = c.nodes;
     s->stats.tris_tested = c.tris;
     s->stats.lit_samples = c.lit;
+    s->stats.unqueued_rays = c.unqueued;
     s->stats.scene_bytes = (uint64_t)s->n_tris * 48 + (s->nodes4.empty() ? s->nodes.size() * sizeof(pt_bvh_node) : s->nodes4.size() * sizeof(pt_bvh_node4));
     s->stats.tree_width = s->nodes4.empty() ? 2u : 4u;
     s->stats.stack_need = s->stack_need;
+    s->stats.two_bounce = s->dev.fuse01 && s->dev.lds_scene && s->dev.fuse;
+    s->stats.packet_primary = s->dev.packet_primary != 0;
     *out = s->stats;
     return PT_OK;
 }

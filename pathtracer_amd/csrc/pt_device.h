@@ -308,7 +308,7 @@ inline void finish_frame(Frame& fr) {  // (cx0..cy1 are set by the caller; defau
 }
 
 struct Counters {  // device-side statistics (pt_stats)
-    unsigned long long rays, shadow_rays, nodes, tris, lit;
+    unsigned long long rays, shadow_rays, nodes, tris, lit, unqueued;
 };
 
 constexpr int kStackDepth = 32;  // deepest two-child tree accepted (bvh_validate); the builder stays below it

@@ -278,7 +278,10 @@ __global__ void k_count_shadow_rays(const uint32_t* seg_counts, Counters* ctr, b
     unsigned long long n = seg_counts[threadIdx.x * kCtrStride];  // kSegs threads
 #pragma unroll
     for (int d = 32; d; d >>= 1) n += __shfl_down(n, d);
-    if (threadIdx.x == 0 && n) atomicAdd(rays ? &ctr->rays : &ctr->shadow_rays, n);
+    if (threadIdx.x == 0 && n) {
+        atomicAdd(rays ? &ctr->rays : &ctr->shadow_rays, n);
+        if (rays) atomicAdd(&ctr->unqueued, n);  // the rays of bounce 1 of a two-bounce launch: traced, never a queue record
+    }
 }
 void launch_count_shadow_rays(const uint32_t* seg_counts, Counters* ctr, hipStream_t st) {
     hipLaunchKernelGGL(k_count_shadow_rays, dim3(1), dim3(kSegs), 0, st, seg_counts, ctr, false);

@@ -355,7 +355,7 @@ class Scene:
         s = L.pt_stats()
         L.check(L.lib.pt_get_stats(self._h, C.byref(s)))
         out = {k: int(getattr(s, k)) for k in ("samples", "rays", "shadow_rays", "nodes_visited", "tris_tested", "lit_samples",
-                                               "scene_bytes", "tree_width", "stack_need")}
+                                               "scene_bytes", "tree_width", "stack_need", "two_bounce", "packet_primary", "unqueued_rays")}
         out["kernel"] = {L.KERNEL_NAMES[i]: {"launches": int(s.kernel[i].launches), "ms": float(s.kernel[i].ms)}
                          for i in range(L.PT_K_COUNT)}
         return out

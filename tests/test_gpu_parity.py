@@ -487,6 +487,8 @@ def test_two_bounce_kernel_is_bitwise_identical(gpu, name):
         assert a.tobytes() == b.tobytes(), (name, cfg)
         sa, sb = one.stats(), two.stats()
         assert (sa["rays"], sa["shadow_rays"], sa["samples"]) == (sb["rays"], sb["shadow_rays"], sb["samples"]), (name, cfg)
+        # the rays of bounce 1 never exist as queue records in the two-bounce launch
+        assert sa["unqueued_rays"] == 0 and (sb["unqueued_rays"] > 0) == (cfg.bounces >= 2)
         assert auto.render(cfg).tobytes() == a.tobytes()
     cfg = pt.Config(width=211, height=97, samples_pr_pixel=5, bounces=3, seed=4, nee=True, spp_per_batch=2)
     whole = one.render(cfg)
