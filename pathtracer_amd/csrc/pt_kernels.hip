@@ -329,6 +329,17 @@ void launch_texture_lookup(const Scene& sc, uint32_t tex, const double* uv, cons
 
 }  // namespace ptd
 
+#ifdef PT_VOTE_PROFILE  // diagnostic build: scripts/diag/vote_profile.py
+extern "C" int pt_debug_vote_profile(unsigned long long* out, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ptd::g_vote_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 2;
+    if (reset) {
+        const unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ptd::g_vote_prof), z, sizeof(z)) != hipSuccess) return 3;
+    }
+    return 0;
+}
+#endif
 extern "C" void pt_rng_uniform2(uint64_t seed, uint32_t pixel, uint64_t sample, uint32_t bounce, uint32_t stream,
                                 double out[2]) {
     ptd::uniform2(seed, pixel, sample, bounce, stream, out[0], out[1]);

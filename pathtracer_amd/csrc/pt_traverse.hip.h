@@ -260,6 +260,12 @@ __device__ __forceinline__ int wide_pop(const WideStack& st, int& sp) {
     if (__builtin_expect(sp >= kWideLds, 0)) ref = st.spill[sp - kWideLds];
     return ref;
 }
+#ifdef PT_VOTE_PROFILE  // diagnostic build (scripts/diag/vote_profile.py): where the lanes of the vote loop go
+__device__ unsigned long long g_vote_prof[16];
+#define PT_VP(i, v) vp[i] += (v)
+#else
+#define PT_VP(i, v)
+#endif
 // One step at a four-wide node: the four boxes are tested together (one float4 per plane), the children
 // that are hit are ordered by entry distance with a 5-comparator network on (distance bits, child) pairs
 // (a miss has the largest key), the nearest becomes the next node and the others go on the stack,
@@ -297,6 +303,16 @@ __device__ __forceinline__ int node4_step(const Scene& sc, int cur, const RayF& 
         key[a] = ka_; key[b] = kb_; ch[a] = ca_; ch[b] = cb_; }
     PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
 #undef PT_CSWAP
+#ifdef PT_VOTE_PROFILE
+    {
+        const unsigned long long m_ = __ballot(key[0] == 0xFFFFFFFFu), a_ = __ballot(true);
+        const unsigned long long h2_ = __ballot(key[1] != 0xFFFFFFFFu), h3_ = __ballot(key[2] != 0xFFFFFFFFu), h4_ = __ballot(key[3] != 0xFFFFFFFFu);
+        if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(a_)) {
+            atomicAdd(&g_vote_prof[14], (unsigned long long)__popcll(m_));
+            atomicAdd(&g_vote_prof[15], (unsigned long long)(__popcll(h2_) + __popcll(h3_) + __popcll(h4_)));
+        }
+    }
+#endif
     if (key[0] == 0xFFFFFFFFu) return wide_pop<STRIDE>(st, sp);
     // the other hits (a prefix of key[1..3]) go on the stack, farthest first
     const int n = (key[1] != 0xFFFFFFFFu) + (key[2] != 0xFFFFFFFFu) + (key[3] != 0xFFFFFFFFu);
@@ -389,6 +405,10 @@ __device__ __forceinline__ void trace_range_vote(const Scene& sc, uint32_t begin
     double t_min = 0., t_max = 0.;
     float t_min32 = 0.f, t_max32 = 0.f;  // t_min rounded down, t_max rounded up (slab32)
     int sp = 0, cur = kDone;
+#ifdef PT_VOTE_PROFILE
+    unsigned long long vp[16] = {};
+    auto vp_flush = [&]() { if ((threadIdx.x & 63u) == 0) for (int k = 0; k < 16; ++k) if (vp[k]) atomicAdd(&g_vote_prof[k], vp[k]); };
+#endif
     // Two nested loops.  The inner one runs node and triangle phases, in which the ray itself (o, d, rf,
     // t_min) is loop-invariant: only the traversal state changes, so the compiler keeps the ray in place
     // (with the fetch in the same loop every trip paid ~25 register copies at the loop's merge point).
@@ -410,18 +430,33 @@ __device__ __forceinline__ void trace_range_vote(const Scene& sc, uint32_t begin
             n_ret = __popcll(m_ret);
             // (plain majority: weighting the three counts 3:2:2, 2:1:2, 2:3:3 or 1:1:2 measured 0-3.5 % slower)
             if (n_node >= n_tri && n_node >= n_ret) {
-                if (n_node == 0) return;  // nothing left in the range
+                if (n_node == 0) {
+#ifdef PT_VOTE_PROFILE
+                    vp_flush();
+#endif
+                    return;  // nothing left in the range
+                }
+                PT_VP(0, 1); PT_VP(1, n_node); PT_VP(8, n_tri); PT_VP(9, n_ret);
                 if (is_node) {
                     if (WIDE) cur = node4_step<STATS, kTravBlock>(sc, cur, rf, t_min32, t_max32, wst, sp, n_nodes);
                     else cur = node_step<DEPTH, STATS>(sc, cur, rf, t_min32, t_max32, stk, sp, n_nodes);
                 }
                 // a wave with at least kVoteDouble lanes at inner nodes takes a second node step before it votes again (the
                 // vote costs ~15 instructions a trip; thresholds 16 / 24 / 32 / 48: extend -2.1 / -2.0 / -1.8 / -0.7 %)
+                PT_VP(2, n_node >= kVoteDouble); PT_VP(3, n_node >= kVoteDouble ? __popcll(__ballot(cur >= 0)) : 0);
                 if (n_node >= kVoteDouble && cur >= 0) {
                     if (WIDE) cur = node4_step<STATS, kTravBlock>(sc, cur, rf, t_min32, t_max32, wst, sp, n_nodes);
                     else cur = node_step<DEPTH, STATS>(sc, cur, rf, t_min32, t_max32, stk, sp, n_nodes);
                 }
             } else if (n_tri >= n_ret) {
+#ifdef PT_VOTE_PROFILE
+                {
+                    const uint32_t c_ = is_tri ? (((uint32_t)~cur) & 7u) + 1u : 0u;
+                    uint32_t mx = 0, sm = 0;
+                    for (int l = 0; l < 64; ++l) { const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)c_, l); mx = max(mx, v); sm += v; }
+                    PT_VP(4, 1); PT_VP(5, n_tri); PT_VP(6, mx); PT_VP(7, sm); PT_VP(10, n_node); PT_VP(11, n_ret);
+                }
+#endif
                 if (is_tri) {
                     const uint32_t code = (uint32_t)~cur, first = code >> 3, cnt = (code & 7u) + 1u;
                     bool stop = false;
@@ -449,6 +484,7 @@ __device__ __forceinline__ void trace_range_vote(const Scene& sc, uint32_t begin
                 break;  // the retire phase has the most lanes
             }
         }
+        PT_VP(12, 1); PT_VP(13, n_ret);
         if (is_ret) {
             if (busy) done(idx, best, t_max);
             busy = false;
