@@ -586,6 +586,11 @@ static int scene_create_impl(const pt_scene_desc* d, int device_id, const pt_sce
     if (s->depth > 8) {  // deep: the kernels walk four-wide nodes (pt_bvh.cpp bvh_collapse4)
         rc = pth::bvh_collapse4(s->nodes, (uint32_t)ptd::kWideStack, s->nodes4, s->stack_need, 85u /* three levels breadth-first: more than any build holds in LDS */);
         if (rc != PT_OK) { set_error("four-wide collapse failed: stack need %u > %d", s->stack_need, ptd::kWideStack); return rc; }
+        // the traversal addresses a node's planes as base + 32-bit byte offset (pt_traverse.hip.h node4_step)
+        if (s->nodes4.size() >= ((size_t)1 << 25)) {
+            set_error("%zu four-wide nodes: the traversal addresses at most 2^25", s->nodes4.size());
+            return PT_ERR_UNSUPPORTED;
+        }
         if ((rc = upload(s->d_nodes4, s->nodes4.data(), s->nodes4.size())) != PT_OK) return rc;
     } else {
         s->stack_need = s->depth;

@@ -91,6 +91,13 @@ struct RayF {
     float clx, cly, clz;  // fl(ol * i), ol = fl(o + E): subtracted from lo * i
     float chx, chy, chz;  // fl(oh * i), oh = fl(o - E): subtracted from hi * i
     float ix, iy, iz;     // i = fl(1 / d), magnitude capped at 2^100
+    // Four-wide nodes (node4_step): which plane of an axis the ray meets first is known from the sign of i, so
+    // the step loads "near" and "far" planes through these per-ray byte offsets into the node instead of loading lo
+    // and hi and taking min / max of every pair (6 v_min / v_max per box).  fma is monotone in each operand and
+    // lo <= hi, cl >= ch for i >= 0 (the reverse for i < 0), so the near value IS min(a, b) of slab32, bit for bit.
+    uint32_t nx, ny, nz;  // near plane's float4: 0 / 16 / 32 (lo) or 48 / 64 / 80 (hi); far = near ^ 48 / 80 / 112
+    float cnx, cny, cnz;  // the near plane's c (cl or ch)
+    float cfx, cfy, cfz;  // the far plane's
 };
 // The plane distances are formed as fma(plane, i, -c), c = fl(origin * i): one instruction per plane, and
 // i itself in f32: i = rcp32(fl32(d)) = (1 / d)(1 + e), |e| <= 3 u (the conversion, and v_rcp_f32's 1 ulp =
@@ -118,6 +125,10 @@ __device__ __forceinline__ RayF make_rayf(D3 o, D3 d) {
     if (!(fmax(fmax(fabs(d.x), fabs(d.y)), fabs(d.z)) >= 0x1p-60)) r.ix = r.iy = r.iz = __builtin_nanf("");  // no cull
     r.clx = olx * r.ix; r.cly = oly * r.iy; r.clz = olz * r.iz;
     r.chx = ohx * r.ix; r.chy = ohy * r.iy; r.chz = ohz * r.iz;
+    const bool px = !(r.ix < 0.f), py = !(r.iy < 0.f), pz = !(r.iz < 0.f);  // (NaN i: no cull either way)
+    r.nx = px ? 0u : 48u; r.ny = py ? 16u : 64u; r.nz = pz ? 32u : 80u;
+    r.cnx = px ? r.clx : r.chx; r.cny = py ? r.cly : r.chy; r.cnz = pz ? r.clz : r.chz;
+    r.cfx = px ? r.chx : r.clx; r.cfy = py ? r.chy : r.cly; r.cfz = pz ? r.chz : r.clz;
     return r;
 }
 __device__ __forceinline__ bool slab32(float lox, float loy, float loz, float hix, float hiy, float hiz, const RayF& r,
@@ -273,23 +284,34 @@ __device__ unsigned long long g_vote_prof[16];
 template <bool STATS, int STRIDE>
 __device__ __forceinline__ int node4_step(const Scene& sc, int cur, const RayF& rf, float t_min, float t_max,
                                           const WideStack& st, int& sp, uint32_t& n_nodes) {
-    float4 lx, ly, lz, hx, hy, hz, cf;
+    // near / far planes of the three axes through the ray's offsets (RayF::nx..): the node's byte offset fits 32 bits
+    // (scene_create refuses a tree of 2^25 four-wide nodes), so the loads are base + 32-bit offset
+    float4 px, py, pz, qx, qy, qz, cf;
+    const uint32_t nb = (uint32_t)cur << 7;
+    const uint32_t ax = nb | rf.nx, ay = nb | rf.ny, az = nb | rf.nz;
     if (kTopNodes > 0 && cur < st.top.n) {  // the top of the tree lives in LDS
-        LdsF4 np = st.top.p + cur * 8;
-        lx = ldsf4(np, 0); ly = ldsf4(np, 1); lz = ldsf4(np, 2); hx = ldsf4(np, 3); hy = ldsf4(np, 4); hz = ldsf4(np, 5); cf = ldsf4(np, 6);
+        typedef __attribute__((address_space(3))) const char* LdsB;
+        LdsB b = (LdsB)st.top.p;
+        auto ld = [&](uint32_t off) { const V4f v = *(LdsF4)(b + off); return make_float4(v.x, v.y, v.z, v.w); };
+        px = ld(ax); py = ld(ay); pz = ld(az); qx = ld(ax ^ 48u); qy = ld(ay ^ 80u); qz = ld(az ^ 112u); cf = ld(nb | 96u);
     } else {
-        const float4* np = sc.nodes4 + (size_t)cur * 8;
-        lx = np[0]; ly = np[1]; lz = np[2]; hx = np[3]; hy = np[4]; hz = np[5]; cf = np[6];
+        const char* b = reinterpret_cast<const char*>(sc.nodes4);
+        auto ld = [&](uint32_t off) { return *reinterpret_cast<const float4*>(b + off); };
+        px = ld(ax); py = ld(ay); pz = ld(az); qx = ld(ax ^ 48u); qy = ld(ay ^ 80u); qz = ld(az ^ 112u); cf = ld(nb | 96u);
     }
     const int c[4] = {__float_as_int(cf.x), __float_as_int(cf.y), __float_as_int(cf.z), __float_as_int(cf.w)};
-    const float lox[4] = {lx.x, lx.y, lx.z, lx.w}, loy[4] = {ly.x, ly.y, ly.z, ly.w}, loz[4] = {lz.x, lz.y, lz.z, lz.w};
-    const float hix[4] = {hx.x, hx.y, hx.z, hx.w}, hiy[4] = {hy.x, hy.y, hy.z, hy.w}, hiz[4] = {hz.x, hz.y, hz.z, hz.w};
+    const float nxp[4] = {px.x, px.y, px.z, px.w}, nyp[4] = {py.x, py.y, py.z, py.w}, nzp[4] = {pz.x, pz.y, pz.z, pz.w};
+    const float fxp[4] = {qx.x, qx.y, qx.z, qx.w}, fyp[4] = {qy.x, qy.y, qy.z, qy.w}, fzp[4] = {qz.x, qz.y, qz.z, qz.w};
     uint32_t key[4];
     int ch[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        float tn;
-        const bool hit = slab32(lox[k], loy[k], loz[k], hix[k], hiy[k], hiz[k], rf, t_min, t_max, tn) && c[k] != PT_BVH_EMPTY;
+        // slab32 with the pairs' min / max resolved by the ray's signs
+        const float tn = fmaxf(fmaxf(__builtin_fmaf(nxp[k], rf.ix, -rf.cnx), __builtin_fmaf(nyp[k], rf.iy, -rf.cny)),
+                               fmaxf(__builtin_fmaf(nzp[k], rf.iz, -rf.cnz), t_min));
+        const float tf = fminf(fminf(__builtin_fmaf(fxp[k], rf.ix, -rf.cfx), __builtin_fmaf(fyp[k], rf.iy, -rf.cfy)),
+                               fminf(__builtin_fmaf(fzp[k], rf.iz, -rf.cfz), t_max));
+        const bool hit = tn <= tf && c[k] != PT_BVH_EMPTY;
         if (STATS) n_nodes += c[k] != PT_BVH_EMPTY;
         // tn >= t_min; for the usual t_min >= 0 its bits order like unsigned integers (a negative t_min only
         // perturbs the visiting order)
