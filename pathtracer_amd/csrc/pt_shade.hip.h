@@ -926,7 +926,9 @@ template <int DEPTH, bool FIRST, bool LAST, bool NEE, int MATS, bool LDS = false
 // step above the 96 that let a fifth wave in; bounded to 5 they spill 36-92 B per lane and still gain (textured
 // Test.obj 4K 22.5 -> 24.4 Gsamples/s, with NEE 12.8 -> 13.6).  The untextured kernels fit already; bounding
 // them too measured -0.4 ... -4 % on CornellBox and 0 on glossy_planes.
-__global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), ((MATS & 1) ? PT_TEX_WAVES : 1)) void k_path(Scene gsc, Frame fr, uint32_t bounce, Queue in, Live live, Queue out,
+// The deep-tree kernels sit at 95-97 VGPRs without a bound: asked for five waves they stay at 96 (the NEE primary
+// kernel took 97 after a change to the node step and lost its fifth wave: +6 % time).
+__global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), (((MATS & 1) || DEPTH > 8) ? PT_TEX_WAVES : 1)) void k_path(Scene gsc, Frame fr, uint32_t bounce, Queue in, Live live, Queue out,
                                                  Push out_push, ShadowQueue sq, Push sq_push, Sample3 ls,
                                                  Counters* ctr, Push mid_push) {
     static_assert(!F01 || (FIRST && !LAST && LDS), "the two-bounce form is the primary launch of a scene in LDS");
@@ -1042,8 +1044,10 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), ((MATS & 1) ? PT_TE
                 const uint32_t lg = fr.grp_log2, frame = fdiv(begin, fr.div_pixels);
                 packet = begin - ((frame >> lg) << lg) * fr.n_tile_pixels < (fr.n8 << lg);
             }
+            const RayF prf = make_rayf(o, d);
+            packet = packet && packet_signs_agree(prf, on_screen);
             if (packet)
-                leaf = traverse_packet4<false>(sc, o, d, 1e-5, t, on_screen, stack, top, nn, nt);
+                leaf = traverse_packet4<false>(sc, o, d, prf, 1e-5, t, on_screen, stack, top, nn, nt);
             else if (on_screen)
                 leaf = (FIRST && (LDS || sc.eye_nodes)) ? traverse_eye<DEPTH, kPathBlock>(sc, d, 1e-5, t, stack + threadIdx.x)
                                                : traverse<DEPTH, false, false, kPathBlock, LDS>(sc, o, d, 1e-5, t, stack + threadIdx.x, nn, nt, top);

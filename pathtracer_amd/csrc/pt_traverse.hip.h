@@ -608,35 +608,49 @@ __device__ __forceinline__ uint32_t traverse(const Scene& sc, D3 o, D3 d, double
 // triangle tests with its own t_max, and a superset of the leaves it would have opened alone is opened, so its
 // closest hit (and the lowest-id tie rule) is what traverse() finds: ids and distances are bit-identical (tested).
 // `ustk`: kWideStack ints of LDS for the wave.  Lanes with active == false hit nothing.
+// The active lanes must agree on the sign of every direction component (packet_signs_agree; one pixel's jitter apart
+// they nearly always do): the near and far planes of a node are then the same float4s for the whole wave.
+__device__ __forceinline__ bool packet_signs_agree(const RayF& rf, bool active) {
+    const unsigned long long act = __ballot(active);
+    const unsigned long long sx = __ballot(active && rf.nx != 0u), sy = __ballot(active && rf.ny != 16u), sz = __ballot(active && rf.nz != 32u);
+    return (sx == 0 || sx == act) && (sy == 0 || sy == act) && (sz == 0 || sz == act);
+}
 template <bool STATS>
-__device__ __forceinline__ uint32_t traverse_packet4(const Scene& sc, D3 o, D3 d, double t_min, double& t_max, bool active,
+__device__ __forceinline__ uint32_t traverse_packet4(const Scene& sc, D3 o, D3 d, const RayF& rf, double t_min, double& t_max, bool active,
                                                      int* ustk, TopNodes top, uint32_t& n_nodes, uint32_t& n_tris) {
     uint32_t best = PT_MISS, best_id = PT_MISS;
     if (sc.n_prims && active) prims_closest(sc, o, d, t_min, t_max, best, best_id);
     if (sc.n_nodes == 0 || !__ballot(active)) return best;
-    const RayF rf = make_rayf(o, d);
     const float t_min32 = f32_down(t_min);
     float t_max32 = active ? f32_up(t_max) : -1.f;   // below t_min: every slab test fails
     int sp = 0, cur = 0;                              // wave-uniform
+    // the float4 of an axis' near plane within a node (lo: 0 / 1 / 2, hi: 3 / 4 / 5), the same for every active lane
+    const int inx = __ballot(active && rf.nx != 0u) ? 3 : 0, iny = __ballot(active && rf.ny != 16u) ? 4 : 1,
+              inz = __ballot(active && rf.nz != 32u) ? 5 : 2;
     for (;;) {
         while (cur >= 0) {
-            float4 lx, ly, lz, hx, hy, hz, cf;
+            // near and far planes by wave-uniform index (packet_signs_agree; RayF::nx): no min / max of lo / hi pairs
+            float4 px, py, pz, qx, qy, qz, cf;
             if (kTopNodes > 0 && cur < top.n) {
                 LdsF4 np = top.p + cur * 8;
-                lx = ldsf4(np, 0); ly = ldsf4(np, 1); lz = ldsf4(np, 2); hx = ldsf4(np, 3); hy = ldsf4(np, 4); hz = ldsf4(np, 5); cf = ldsf4(np, 6);
+                px = ldsf4(np, inx); py = ldsf4(np, iny); pz = ldsf4(np, inz);
+                qx = ldsf4(np, inx ^ 3); qy = ldsf4(np, iny ^ 5); qz = ldsf4(np, inz ^ 7); cf = ldsf4(np, 6);
             } else {
                 const float4* np = sc.nodes4 + (size_t)cur * 8;
-                lx = np[0]; ly = np[1]; lz = np[2]; hx = np[3]; hy = np[4]; hz = np[5]; cf = np[6];
+                px = np[inx]; py = np[iny]; pz = np[inz]; qx = np[inx ^ 3]; qy = np[iny ^ 5]; qz = np[inz ^ 7]; cf = np[6];
             }
             const int c[4] = {__float_as_int(cf.x), __float_as_int(cf.y), __float_as_int(cf.z), __float_as_int(cf.w)};
-            const float lox[4] = {lx.x, lx.y, lx.z, lx.w}, loy[4] = {ly.x, ly.y, ly.z, ly.w}, loz[4] = {lz.x, lz.y, lz.z, lz.w};
-            const float hix[4] = {hx.x, hx.y, hx.z, hx.w}, hiy[4] = {hy.x, hy.y, hy.z, hy.w}, hiz[4] = {hz.x, hz.y, hz.z, hz.w};
+            const float pxs[4] = {px.x, px.y, px.z, px.w}, pys[4] = {py.x, py.y, py.z, py.w}, pzs[4] = {pz.x, pz.y, pz.z, pz.w};
+            const float qxs[4] = {qx.x, qx.y, qx.z, qx.w}, qys[4] = {qy.x, qy.y, qy.z, qy.w}, qzs[4] = {qz.x, qz.y, qz.z, qz.w};
             uint32_t key[4];
             int ch[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float tn;
-                const bool hit = slab32(lox[k], loy[k], loz[k], hix[k], hiy[k], hiz[k], rf, t_min32, t_max32, tn);
+                const float tn = fmaxf(fmaxf(__builtin_fmaf(pxs[k], rf.ix, -rf.cnx), __builtin_fmaf(pys[k], rf.iy, -rf.cny)),
+                                       fmaxf(__builtin_fmaf(pzs[k], rf.iz, -rf.cnz), t_min32));
+                const float tf = fminf(fminf(__builtin_fmaf(qxs[k], rf.ix, -rf.cfx), __builtin_fmaf(qys[k], rf.iy, -rf.cfy)),
+                                       fminf(__builtin_fmaf(qzs[k], rf.iz, -rf.cfz), t_max32));
+                const bool hit = tn <= tf;
                 if (STATS) n_nodes += active && c[k] != PT_BVH_EMPTY;
                 const unsigned long long m = __ballot(hit);
                 ch[k] = __builtin_amdgcn_readfirstlane(c[k]);
