@@ -329,6 +329,12 @@ void launch_texture_lookup(const Scene& sc, uint32_t tex, const double* uv, cons
 
 }  // namespace ptd
 
+#ifdef PT_PATH_PROFILE  // diagnostic build: scripts/diag/path_profile.py
+extern "C" int pt_debug_path_cut(int cut) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(ptd::g_path_cut), &cut, sizeof(int)) == hipSuccess ? 0 : 2;
+}
+#endif
 #ifdef PT_VOTE_PROFILE  // diagnostic build: scripts/diag/vote_profile.py
 extern "C" int pt_debug_vote_profile(unsigned long long* out, int reset) {
     if (hipDeviceSynchronize() != hipSuccess) return 1;

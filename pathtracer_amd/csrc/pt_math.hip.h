@@ -125,6 +125,19 @@ __device__ __forceinline__ void slot_sp(const Frame& fr, uint32_t lg, uint32_t s
         p = fr.n8 + (rr - f * rest);
     }
 }
+// what the shading needs to know of a slot: its frame within the batch, its pixel (tile column, image row, index
+// in the image).  ~50 integer instructions with two data-dependent branches, so a kernel computes it once per
+// slot and hands it to every vertex it shades (the compiler does not merge the copies by itself).
+struct SlotId {
+    uint32_t s, tx, gy, pixel;
+};
+__device__ __forceinline__ SlotId slot_id(const Frame& fr, uint32_t slot) {
+    uint32_t s, p, tx, ty;
+    slot_sp(fr, fr.grp_log2, slot, s, p);
+    slot_pixel(fr, p, tx, ty);
+    const uint32_t gy = frame_row(fr, ty);
+    return {s, tx, gy, gy * fr.width + fr.x0 + tx};
+}
 __device__ __forceinline__ size_t sp_slot(const Frame& fr, uint32_t lg, uint32_t s, uint32_t p) {
     if (lg == 0) return (size_t)s * fr.n_tile_pixels + p;
     const uint32_t g = s >> lg, f = s & ((1u << lg) - 1u);

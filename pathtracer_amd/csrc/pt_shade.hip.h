@@ -575,17 +575,12 @@ __device__ __forceinline__ PathRec load_rec(const Queue& in, uint32_t i) {
 //           (r.lit holds it): the second vertex of the kernel that traces bounces 0 and 1 in one go (k_path F01).
 template <bool FIRST, bool LAST, bool NEE, int MATS, bool FUSED, bool DIFFS = false, bool OWN = false>
 __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, uint32_t bounce, const Queue& in,
-                                             uint32_t i, PathRec rec, uint32_t leaf, double t_hit, D3 o, D3 d,
-                                             const Sample3& ls, ShadeOut& r) {
+                                             uint32_t i, PathRec rec, const SlotId& id /* slot_id(fr, rec.slot) */, uint32_t leaf,
+                                             double t_hit, D3 o, D3 d, const Sample3& ls, ShadeOut& r) {
     constexpr bool TEX = (MATS & 1) != 0, SPEC = (MATS & 2) != 0;
     const uint32_t slot = rec.slot;
     r.slot = slot;
-    uint32_t s, p;
-    slot_sp(fr, fr.grp_log2, slot, s, p);
-    uint32_t ty, tx;
-    slot_pixel(fr, p, tx, ty);
-    const uint32_t gy_ = frame_row(fr, ty);
-    uint32_t pixel = gy_ * fr.width + fr.x0 + tx;
+    const uint32_t s = id.s, tx = id.tx, gy_ = id.gy, pixel = id.pixel;
     uint64_t sample = fr.sample_base + s;
     constexpr bool kNeedRay = !LAST || NEE;
     if (!FUSED) {  // FUSED: the caller traced the ray in this kernel and still holds it
@@ -860,7 +855,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
             ShadeOut r;
             uint32_t leaf = hits.tri[i];
             double t = (leaf != PT_MISS && NEE) ? hits.t[i] : 0.;
-            shade_vertex<FIRST, LAST, NEE, MATS, false, DIFFS>(sc, fr, bounce, in, i, load_rec<FIRST, NEE>(in, i), leaf, t,
+            const PathRec rec = load_rec<FIRST, NEE>(in, i);
+            shade_vertex<FIRST, LAST, NEE, MATS, false, DIFFS>(sc, fr, bounce, in, i, rec, slot_id(fr, rec.slot), leaf, t,
                                                                 mk(0., 0., 0.), mk(0., 0., 0.), ls, r);
         }
     }
@@ -875,7 +871,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
         uint32_t leaf = hits.tri[i];
         // the hit distance is only needed (and only loaded) where the vertex is shaded in full
         double t = (leaf != PT_MISS && (!LAST || NEE)) ? hits.t[i] : 0.;
-        shade_vertex<FIRST, LAST, NEE, MATS, false, DIFFS>(sc, fr, bounce, in, i, load_rec<FIRST, NEE>(in, i), leaf, t,
+        const PathRec rec = load_rec<FIRST, NEE>(in, i);
+        shade_vertex<FIRST, LAST, NEE, MATS, false, DIFFS>(sc, fr, bounce, in, i, rec, slot_id(fr, rec.slot), leaf, t,
                                                             mk(0., 0., 0.), mk(0., 0., 0.), ls, r);
     }
     if (FIRST) store_lit(ls, i - (threadIdx.x & 63u), n, r.lit);
@@ -903,6 +900,12 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
 #endif
 // (with the scene in LDS - LDS below - 256 threads: 64 / 128 / 256 / 512 / 1024 -> 19.5 / 24.0 / 25.5 /
 // 24.0 / 17.4 Gsamples/s on CornellBox; the copy is shared by twice the rays)
+#ifdef PT_PATH_PROFILE  // diagnostic build (scripts/diag/path_profile.py): the path kernels stop after section g_path_cut
+__device__ int g_path_cut;  // 0 = run everything (clock stamps proved useless: the compiler moves the work across them)
+#define PT_CUT(k) (path_cut == (k))
+#else
+#define PT_CUT(k) false
+#endif
 template <int DEPTH, bool LDS = false> struct PathBlock {
     static constexpr int value = DEPTH <= 8 ? (LDS ? 256 : 128) : PT_PATH_BLOCK_DEEP;
 };
@@ -969,6 +972,9 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), (((MATS & 1) || DEP
     r.n_o = r.n_d = r.n_T = r.s_d = r.s_c = mk(0., 0., 0.);
     uint32_t n_mid = 0, n_shadow = 0;  // F01: this lane's path reached its second vertex; light samples it took
     const bool sparse = LAST && !FIRST && live.counts && live.sparse;
+#ifdef PT_PATH_PROFILE
+    const int path_cut = g_path_cut;
+#endif
     for (uint32_t blk = blockIdx.x;; blk += gridDim.x) {  // one pass, except over a sparse queue
         uint32_t begin, end;
         if (sparse) {  // few live entries: this small grid enumerates the live blocks
@@ -1015,12 +1021,10 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), (((MATS & 1) || DEP
         if (i < end) {
             D3 o = mk(0., 0., 0.), d = o;
             bool on_screen = true;  // FIRST: the pixel lies inside the scene's screen bounds (Frame::cx0..)
+            SlotId id{0, 0, 0, 0};  // FIRST: of slot i, here; otherwise of the record's slot, once that is loaded
             if (FIRST) {
-                uint32_t s, p;
-                slot_sp(fr, fr.grp_log2, i, s, p);
-                uint32_t ty, tx;
-                slot_pixel(fr, p, tx, ty);
-                const uint32_t gx = fr.x0 + tx, gy = frame_row(fr, ty);
+                id = slot_id(fr, i);
+                const uint32_t gx = fr.x0 + id.tx, gy = id.gy, s = id.s;
                 on_screen = gx >= fr.cx0 && gx < fr.cx1 && gy >= fr.cy0 && gy < fr.cy1;
                 if (on_screen) {
                     PixelArgs a = pixel_args(gx, gy, fr.width, fr.height, fr.jitter[2 * s], fr.jitter[2 * s + 1], fr.aspect);
@@ -1051,7 +1055,11 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), (((MATS & 1) || DEP
             else if (on_screen)
                 leaf = (FIRST && (LDS || sc.eye_nodes)) ? traverse_eye<DEPTH, kPathBlock>(sc, d, 1e-5, t, stack + threadIdx.x)
                                                : traverse<DEPTH, false, false, kPathBlock, LDS>(sc, o, d, 1e-5, t, stack + threadIdx.x, nn, nt, top);
-            shade_vertex<FIRST, LAST, NEE, MATS, true>(sc, fr, bounce, in, i, rec, leaf, t, o, d, ls, r);
+            if (PT_CUT(1)) { if (leaf == 0x7ffffff0u && t == 0.5) r.lit = true; leaf = PT_MISS; on_screen = false; }
+            if (!FIRST) id = slot_id(fr, rec.slot);
+            if (!PT_CUT(1))
+            shade_vertex<FIRST, LAST, NEE, MATS, true>(sc, fr, bounce, in, i, rec, id, leaf, t, o, d, ls, r);
+            if (PT_CUT(2)) r.alive = false;
             // the light sample's visibility, in place: the shadow ray never leaves the registers
             // (84 B written + read per shadow ray and one launch per bounce otherwise).  Same order
             // of additions as the shadow kernel's: the vertex's emission first, then its light sample.
@@ -1073,7 +1081,10 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), (((MATS & 1) || DEP
                     n_mid = 1;
                     double t2 = 1.7976931348623157e308;
                     const uint32_t leaf2 = traverse<DEPTH, false, false, kPathBlock, LDS>(sc, o2, d2, 1e-5, t2, stack + threadIdx.x, nn, nt, top);
-                    shade_vertex<false, false, NEE, MATS, true, false, true>(sc, fr, bounce + 1, in, i, rec2, leaf2, t2, o2, d2, ls, r);
+                    if (PT_CUT(3)) { if (leaf2 == 0x7ffffff0u && t2 == 0.5) r.lit = true; }
+                    else
+                    shade_vertex<false, false, NEE, MATS, true, false, true>(sc, fr, bounce + 1, in, i, rec2, id, leaf2, t2, o2, d2, ls, r);
+                    if (PT_CUT(4)) r.alive = false;
                     if (NEE && r.shadow) trace_shadow(true);
                     n_shadow += r.shadow;
                 }
