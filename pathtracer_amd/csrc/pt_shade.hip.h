@@ -508,6 +508,26 @@ __device__ __forceinline__ uint32_t compact_wave(bool alive, uint32_t* counter) 
 // producer: it is never queued, read back or traced, and the image is bit-identical.  Non-finite
 // rays and throughputs are kept (NaN * 0 is not 0; the reference accumulates those).
 __device__ __forceinline__ bool finite3(D3 a) { return (a.x - a.x == 0.) && (a.y - a.y == 0.) && (a.z - a.z == 0.); }
+// The cull may keep a ray that then misses (it is traced and adds nothing), never drop one that hits: so it runs
+// tri_test_core's rejects without its three divisions (a wave of 64 incoherent rays nearly always holds a lane that
+// would need them).  False only where tri_test_core(p, d, 1e-5, f64::MAX) is certain to reject:
+__device__ __forceinline__ bool tri_may_hit(const TriPre& p, D3 d) {
+    const double dn = dot(d, p.normal);
+    if (fabs(dn) < 1.0e-12) return false;      // its own first reject
+    if (!(fabs(dn) <= 0x1p500)) return true;   // outside the guard of the sign tests (or NaN): not decided here
+    const D3 tmp = cross(p.vo, d);
+    const double a = dot(tmp, p.e1), b = dot(tmp, p.e0);
+    const bool dneg = dn < 0.;
+    if (fabs(a) >= 0x1p-500 && (a < 0.) != dneg) return false;          // v < 0
+    if (fabs(b) >= 0x1p-500 && (b < 0.) != dneg) return false;          // w < 0
+    if (fabs(p.num) >= 0x1p-500 && (p.num < 0.) != dneg) return false;  // t < 0
+    // v + w > 1: v = fl(a fl(1 / dn)), w likewise and their rounded sum are within 3 x 2^-53 (relative) of
+    // (a + b) / dn, so a margin of 2^-40 decides it for every rounding (an infinite a or b has v + w = inf)
+    if (fabs(a) + fabs(b) > fabs(dn) * (1. + 0x1p-40)) return false;
+    // t < t_min = 1e-5, the same way (a ray that starts ON an emitter: every path whose vertex is a light)
+    if (fabs(p.num) < fabs(dn) * (1e-5 * (1. - 0x1p-40))) return false;
+    return true;  // (the bands of relative width 2^-40 around v + w = 1 and t = 1e-5 are left to the traversal)
+}
 __device__ __forceinline__ bool may_reach_emitter(const Scene& sc, D3 o, D3 d, D3 T) {
     if (!(finite3(o) && finite3(d) && finite3(T))) return true;
     for (uint32_t k = 0; k < sc.n_emissive; ++k) {
@@ -516,8 +536,7 @@ __device__ __forceinline__ bool may_reach_emitter(const Scene& sc, D3 o, D3 d, D
         p.e0 = ld3(e.e0); p.e1 = ld3(e.e1); p.normal = ld3(e.normal);
         p.vo = ld3(e.v0) - o;
         p.num = dot(p.vo, p.normal);
-        double t, v, w;
-        if (tri_test_core(p, d, 1e-5, 1.7976931348623157e308, t, v, w)) return true;
+        if (tri_may_hit(p, d)) return true;
     }
     return false;
 }
