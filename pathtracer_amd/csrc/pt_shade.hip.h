@@ -1014,7 +1014,9 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), (((MATS & 1) || DEP
             // (the primary bounce walks the eye tables; it needs the general arrays only for shadow rays and uvs)
             constexpr bool kGeneral = !FIRST || NEE || (MATS & 1) || F01;
             if (kGeneral) {
-                for (uint32_t k = threadIdx.x; k < gsc.n_nodes * 4; k += kPathBlock) s_nodes[k] = gsc.nodes[k];
+                // (nodes and eye nodes: plane-major in LDS, pt_traverse.hip.h node_step_lds)
+                for (uint32_t k = threadIdx.x; k < gsc.n_nodes * 16; k += kPathBlock)
+                    reinterpret_cast<float*>(s_nodes)[(k & ~15u) + lds_node_float(k & 15u)] = reinterpret_cast<const float*>(gsc.nodes)[k];
                 for (uint32_t k = threadIdx.x; k < gsc.n_tris * 3; k += kPathBlock) s_tris[k] = gsc.tris[k];
             }
             for (uint32_t k = threadIdx.x; k < gsc.n_tris * 2; k += kPathBlock) s_shade[k] = g_shade[k];
@@ -1030,7 +1032,8 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), (((MATS & 1) || DEP
             if (FIRST) {
                 const float4* g_en = reinterpret_cast<const float4*>(gsc.eye_nodes);
                 const float4* g_et = reinterpret_cast<const float4*>(gsc.eye_tris);
-                for (uint32_t k = threadIdx.x; k < gsc.n_nodes * 4; k += kPathBlock) s_eye_nodes[k] = g_en[k];
+                for (uint32_t k = threadIdx.x; k < gsc.n_nodes * 16; k += kPathBlock)
+                    reinterpret_cast<float*>(s_eye_nodes)[(k & ~15u) + lds_node_float(k & 15u)] = reinterpret_cast<const float*>(g_en)[k];
                 for (uint32_t k = threadIdx.x; k < gsc.n_tris * 7; k += kPathBlock) s_eye_tris[k] = g_et[k];
             }
             __syncthreads();
@@ -1072,7 +1075,7 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), (((MATS & 1) || DEP
             if (packet)
                 leaf = traverse_packet4<false>(sc, o, d, prf, 1e-5, t, on_screen, stack, top, nn, nt);
             else if (on_screen)
-                leaf = (FIRST && (LDS || sc.eye_nodes)) ? traverse_eye<DEPTH, kPathBlock>(sc, d, 1e-5, t, stack + threadIdx.x)
+                leaf = (FIRST && (LDS || sc.eye_nodes)) ? traverse_eye<DEPTH, kPathBlock, LDS>(sc, d, 1e-5, t, stack + threadIdx.x)
                                                : traverse<DEPTH, false, false, kPathBlock, LDS>(sc, o, d, 1e-5, t, stack + threadIdx.x, nn, nt, top);
             if (PT_CUT(1)) { if (leaf == 0x7ffffff0u && t == 0.5) r.lit = true; leaf = PT_MISS; on_screen = false; }
             if (!FIRST) id = slot_id(fr, rec.slot);

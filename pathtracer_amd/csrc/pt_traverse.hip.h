@@ -96,6 +96,7 @@ struct RayF {
     // and hi and taking min / max of every pair (6 v_min / v_max per box).  fma is monotone in each operand and
     // lo <= hi, cl >= ch for i >= 0 (the reverse for i < 0), so the near value IS min(a, b) of slab32, bit for bit.
     uint32_t nx, ny, nz;  // near plane's float4: 0 / 16 / 32 (lo) or 48 / 64 / 80 (hi); far = near ^ 48 / 80 / 112
+    uint32_t hx, hy, hz;  // the same for a two-child node in LDS (node_step_lds): nx / 2 ..; far = near ^ 24 / 40 / 56
     float cnx, cny, cnz;  // the near plane's c (cl or ch)
     float cfx, cfy, cfz;  // the far plane's
 };
@@ -127,6 +128,7 @@ __device__ __forceinline__ RayF make_rayf(D3 o, D3 d) {
     r.chx = ohx * r.ix; r.chy = ohy * r.iy; r.chz = ohz * r.iz;
     const bool px = !(r.ix < 0.f), py = !(r.iy < 0.f), pz = !(r.iz < 0.f);  // (NaN i: no cull either way)
     r.nx = px ? 0u : 48u; r.ny = py ? 16u : 64u; r.nz = pz ? 32u : 80u;
+    r.hx = px ? 0u : 24u; r.hy = py ? 8u : 32u; r.hz = pz ? 16u : 40u;
     r.cnx = px ? r.clx : r.chx; r.cny = py ? r.cly : r.chy; r.cnz = pz ? r.clz : r.chz;
     r.cfx = px ? r.chx : r.clx; r.cfy = py ? r.chy : r.cly; r.cfz = pz ? r.chz : r.clz;
     return r;
@@ -229,6 +231,53 @@ __device__ __forceinline__ int node_step(const Scene& sc, int cur, const RayF& r
     if (sp == 0) return kDone;
     --sp;
     return stk[sp * STRIDE];
+}
+
+// ---- two-child nodes of a scene held in LDS (k_path LDS) ---------------------------------------------------------
+// The kernel's copy of a node (and of an EyeNode) is plane-major: float 2p + k = plane p (lo x y z, hi x y z) of child
+// k, floats 12 and 13 the children; 64 bytes as before.  A ray then reads the near and the far plane of an axis for
+// both children with one 8-byte load each, picked by the sign of its direction (RayF::hx.., as node4_step does):
+// six loads, and no min / max of lo / hi pairs (12 instructions a step).  lds_node_float: where float j of the
+// global layout (child-major: lo xyz, hi xyz of child 0, of child 1, the children) goes.
+__device__ __forceinline__ uint32_t lds_node_float(uint32_t j) { return j < 6u ? 2u * j : (j < 12u ? 2u * (j - 6u) + 1u : j); }
+typedef float V2f __attribute__((ext_vector_type(2)));
+typedef int V2i __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const char* LdsB;
+__device__ __forceinline__ V2f lds_f2(LdsB b, uint32_t off) { return *(const __attribute__((address_space(3))) V2f*)(b + off); }
+__device__ __forceinline__ V2i lds_i2(LdsB b, uint32_t off) { return *(const __attribute__((address_space(3))) V2i*)(b + off); }
+// what a step does once both children are tested (node_step, node_step_lds, traverse_eye)
+template <int DEPTH, int STRIDE>
+__device__ __forceinline__ int two_child_next(bool h0, bool h1, float tn0, float tn1, int c0, int c1, int* stk, int& sp) {
+    if (h0 && h1) {
+        int nearc = c0, farc = c1;
+        if (tn1 < tn0) { nearc = c1; farc = c0; }
+        PT_STACK_CHECK(sp, DEPTH);
+        if (sp < DEPTH) { stk[sp * STRIDE] = farc; ++sp; }
+        return nearc;
+    }
+    if (h0) return c0;
+    if (h1) return c1;
+    if (sp == 0) return kDone;
+    --sp;
+    return stk[sp * STRIDE];
+}
+template <int DEPTH, int STRIDE>
+__device__ __forceinline__ int node_step_lds(const float4* nodes, int cur, const RayF& rf, float t_min, float t_max, int* stk, int& sp) {
+    const LdsB b = (LdsB)nodes;
+    const uint32_t nb = (uint32_t)cur << 6;
+    const V2f px = lds_f2(b, nb | rf.hx), py = lds_f2(b, nb | rf.hy), pz = lds_f2(b, nb | rf.hz);
+    const V2f qx = lds_f2(b, nb | (rf.hx ^ 24u)), qy = lds_f2(b, nb | (rf.hy ^ 40u)), qz = lds_f2(b, nb | (rf.hz ^ 56u));
+    const V2i c = lds_i2(b, nb | 48u);
+    // slab32 with the pairs' min / max resolved by the ray's signs (bit for bit its t_near and its verdict: RayF::nx)
+    const float tn0 = fmaxf(fmaxf(__builtin_fmaf(px.x, rf.ix, -rf.cnx), __builtin_fmaf(py.x, rf.iy, -rf.cny)),
+                            fmaxf(__builtin_fmaf(pz.x, rf.iz, -rf.cnz), t_min));
+    const float tf0 = fminf(fminf(__builtin_fmaf(qx.x, rf.ix, -rf.cfx), __builtin_fmaf(qy.x, rf.iy, -rf.cfy)),
+                            fminf(__builtin_fmaf(qz.x, rf.iz, -rf.cfz), t_max));
+    const float tn1 = fmaxf(fmaxf(__builtin_fmaf(px.y, rf.ix, -rf.cnx), __builtin_fmaf(py.y, rf.iy, -rf.cny)),
+                            fmaxf(__builtin_fmaf(pz.y, rf.iz, -rf.cnz), t_min));
+    const float tf1 = fminf(fminf(__builtin_fmaf(qx.y, rf.ix, -rf.cfx), __builtin_fmaf(qy.y, rf.iy, -rf.cfy)),
+                            fminf(__builtin_fmaf(qz.y, rf.iz, -rf.cfz), t_max));
+    return two_child_next<DEPTH, STRIDE>(tn0 <= tf0 && c.x != PT_BVH_EMPTY, tn1 <= tf1 && c.y != PT_BVH_EMPTY, tn0, tn1, c.x, c.y, stk, sp);
 }
 
 // ---- four-wide nodes (deep trees) -----------------------------------------------------------------------
@@ -559,6 +608,7 @@ __device__ __forceinline__ uint32_t traverse(const Scene& sc, D3 o, D3 d, double
     while (cur != kDone) {
         while (cur >= 0) {
             if (WIDE) cur = node4_step<STATS, STRIDE>(sc, cur, rf, t_min32, t_max32, wst, sp, n_nodes);
+            else if (EDGES) cur = node_step_lds<DEPTH, STRIDE>(sc.nodes, cur, rf, t_min32, t_max32, stk, sp);  // the scene-in-LDS kernel
             else cur = node_step<DEPTH, STATS, STRIDE>(sc, cur, rf, t_min32, t_max32, stk, sp, n_nodes);
         }
         if (cur == kDone) break;
@@ -755,7 +805,8 @@ __global__ void k_build_tri_edges(Scene sc, EyeTri* tris) {
     e.pad = 0;
 }
 // traverse() for a ray that starts at the eye (closest hit only)
-template <int DEPTH, int STRIDE>
+// LDSN: Scene::eye_nodes is the kernel's plane-major copy in LDS (node_step_lds)
+template <int DEPTH, int STRIDE, bool LDSN = false>
 __device__ __forceinline__ uint32_t traverse_eye(const Scene& sc, D3 d, double t_min, double& t_max, int* stk) {
     uint32_t best = PT_MISS, best_id = PT_MISS;
     if (sc.n_prims) prims_closest(sc, ld3(sc.cam.eye), d, t_min, t_max, best, best_id);
@@ -766,8 +817,23 @@ __device__ __forceinline__ uint32_t traverse_eye(const Scene& sc, D3 d, double t
     float t_max32 = f32_up(t_max);
     int sp = 0;
     int cur = 0;
+    // LDSN: near planes by the sign of the direction (an infinite or NaN reciprocal only ever drops a NaN plane from a
+    // max / min, which opens the box)
+    const uint32_t hx = ix < 0.f ? 24u : 0u, hy = iy < 0.f ? 32u : 8u, hz = iz < 0.f ? 40u : 16u;
     while (cur != kDone) {
-        while (cur >= 0) {
+        while (LDSN && cur >= 0) {
+            const LdsB b = (LdsB)sc.eye_nodes;
+            const uint32_t nb = (uint32_t)cur << 6;
+            const V2f px = lds_f2(b, nb | hx), py = lds_f2(b, nb | hy), pz = lds_f2(b, nb | hz);
+            const V2f qx = lds_f2(b, nb | (hx ^ 24u)), qy = lds_f2(b, nb | (hy ^ 40u)), qz = lds_f2(b, nb | (hz ^ 56u));
+            const V2i c = lds_i2(b, nb | 48u);
+            const float tn0 = fmaxf(fmaxf(px.x * ix, py.x * iy), fmaxf(pz.x * iz, t_min32));
+            const float tf0 = fminf(fminf(qx.x * ix, qy.x * iy), fminf(qz.x * iz, t_max32));
+            const float tn1 = fmaxf(fmaxf(px.y * ix, py.y * iy), fmaxf(pz.y * iz, t_min32));
+            const float tf1 = fminf(fminf(qx.y * ix, qy.y * iy), fminf(qz.y * iz, t_max32));
+            cur = two_child_next<DEPTH, STRIDE>(tn0 <= tf0 && c.x != PT_BVH_EMPTY, tn1 <= tf1 && c.y != PT_BVH_EMPTY, tn0, tn1, c.x, c.y, stk, sp);
+        }
+        while (!LDSN && cur >= 0) {
             const EyeNode& n = sc.eye_nodes[cur];
             int c0 = n.child[0], c1 = n.child[1];
             float tn0, tn1;
