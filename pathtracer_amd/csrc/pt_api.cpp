@@ -163,7 +163,7 @@ struct pt_scene {
     std::vector<pt_bvh_node4> nodes4;  // deep trees: the four-wide device tree
     uint32_t stack_need = 0;           // entries the deepest path of the device tree needs
     DevBuf d_nodes4;
-    DevBuf d_nodes, d_tris, d_uvs, d_leaf_of, d_mats, d_texs, d_lights, d_emissive, d_prims, d_tri_shade, d_tri_basis, d_eye_nodes, d_eye_tris, d_tri_edges, d_ctr;
+    DevBuf d_nodes, d_tris, d_uvs, d_leaf_of, d_mats, d_texs, d_lights, d_emissive, d_prims, d_tri_shade, d_tri_basis, d_eye_nodes, d_eye_tris, d_tri_edges, d_nodes_pm, d_eye_nodes_pm, d_ctr;
     std::vector<DevBuf*> d_texels;
     Workspace ws;
     std::mutex mu;
@@ -788,10 +788,19 @@ static int scene_create_impl(const pt_scene_desc* d, int device_id, const pt_sce
     dv.lds_scene = dv.eye_nodes && dv.n_nodes <= (uint32_t)ptd::kLdsScene && d->n_tris <= (uint32_t)ptd::kLdsScene &&
                    d->n_mats <= (uint32_t)ptd::kLdsMats && d->n_prims == 0 && opt(o.lds_scene, true);
     dv.tri_edges = nullptr;
+    dv.nodes_pm = dv.eye_nodes_pm = nullptr;
     if (dv.lds_scene) {
         HIP_TRY(s->d_tri_edges.alloc((size_t)d->n_tris * sizeof(ptd::EyeTri)));
         ptd::launch_build_tri_edges(dv, s->d_tri_edges.as<ptd::EyeTri>(), nullptr);
         dv.tri_edges = s->d_tri_edges.as<ptd::EyeTri>();
+        // the nodes as the path kernel keeps them in LDS
+        static_assert(sizeof(ptd::EyeNode) == 64 && sizeof(pt_bvh_node) == 64, "two-child nodes: 16 floats");
+        HIP_TRY(s->d_nodes_pm.alloc(s->nodes.size() * 64));
+        HIP_TRY(s->d_eye_nodes_pm.alloc(s->nodes.size() * 64));
+        ptd::launch_plane_major(reinterpret_cast<const float*>(dv.nodes), s->d_nodes_pm.as<float>(), dv.n_nodes, nullptr);
+        ptd::launch_plane_major(reinterpret_cast<const float*>(dv.eye_nodes), s->d_eye_nodes_pm.as<float>(), dv.n_nodes, nullptr);
+        dv.nodes_pm = s->d_nodes_pm.as<float4>();
+        dv.eye_nodes_pm = s->d_eye_nodes_pm.as<float4>();
     }
     HIP_TRY(hipDeviceSynchronize());
     for (int a = 0; a < 3; ++a) dv.background[a] = d->background[a];

@@ -124,6 +124,8 @@ struct Scene {
     const EyeTri* eye_tris;
     const EyeTri* tri_edges;    // the same records for the origin (0, 0, 0): e0, e1, e0 x e1 and vo = v0 of every triangle, for
                                 // rays from anywhere (scenes that live in LDS: a ds_read instead of 24 f64 operations per test)
+    const float4* nodes_pm;     // scenes that live in LDS: `nodes` and `eye_nodes` plane-major (pt_traverse.hip.h node_step_lds),
+    const float4* eye_nodes_pm; // 4 x float4 a node, what the path kernel copies into LDS as it is
     const uint32_t* leaf_of;  // global triangle id -> leaf-order index
     const Material* mats;
     const Texture* texs;
@@ -357,6 +359,7 @@ void launch_accumulate(const Frame& fr, Sample3 lsample, const unsigned long lon
 // parity entry points
 void launch_build_eye_tables(const Scene& sc, EyeNode* nodes, EyeTri* tris, hipStream_t st);
 void launch_build_tri_edges(const Scene& sc, EyeTri* tris, hipStream_t st);
+void launch_plane_major(const float* src, float* dst, uint32_t n_nodes, hipStream_t st);  // two-child nodes / EyeNodes -> plane-major
 void launch_build_tri_shade(const Scene& sc, TriShade* out, TriBasis* basis /* or nullptr */, hipStream_t st);
 void launch_build_emitters(const Scene& sc, const uint32_t* leaf, uint32_t n, EmitTri* out, hipStream_t st);
 void launch_leaf_to_global(const Scene& sc, uint32_t* tri, uint32_t n, hipStream_t st);

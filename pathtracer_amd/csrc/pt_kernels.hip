@@ -303,6 +303,14 @@ void launch_build_tri_edges(const Scene& sc, EyeTri* tris, hipStream_t st) {
     if (!sc.n_tris) return;
     hipLaunchKernelGGL(k_build_tri_edges, dim3((sc.n_tris + 255) / 256), dim3(256), 0, st, sc, tris);
 }
+__global__ void k_plane_major(const float* __restrict__ src, float* __restrict__ dst, uint32_t n_floats) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_floats) dst[(k & ~15u) + lds_node_float(k & 15u)] = src[k];
+}
+void launch_plane_major(const float* src, float* dst, uint32_t n_nodes, hipStream_t st) {
+    if (!n_nodes) return;
+    hipLaunchKernelGGL(k_plane_major, dim3((n_nodes * 16 + 255) / 256), dim3(256), 0, st, src, dst, n_nodes * 16);
+}
 void launch_build_emitters(const Scene& sc, const uint32_t* leaf, uint32_t n, EmitTri* out, hipStream_t st) {
     if (!n) return;
     hipLaunchKernelGGL(k_build_emitters, dim3(blocks_for(n)), dim3(kBlock), 0, st, sc, leaf, n, out);

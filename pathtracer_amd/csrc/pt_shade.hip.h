@@ -914,6 +914,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(Scene sc, Frame fr, uint32_t b
 // 64 -> 9.38, 128 -> 11.09, 256 -> 10.93, 512 -> 9.90 Gsamples/s: one-wave workgroups are bound by
 // workgroup dispatch when every wave is short), one wave for deep trees (waves differ 10x in length;
 // LDS and registers are released per wave).
+#ifndef PT_PATH_BLOCK_LDS
+#define PT_PATH_BLOCK_LDS 256  // (512: -2 % on CornellBox, -12 % on glossy_planes; 1024: -32 %)
+#endif
 #ifndef PT_PATH_BLOCK_DEEP
 #define PT_PATH_BLOCK_DEEP 64
 #endif
@@ -926,7 +929,7 @@ __device__ int g_path_cut;  // 0 = run everything (clock stamps proved useless: 
 #define PT_CUT(k) false
 #endif
 template <int DEPTH, bool LDS = false> struct PathBlock {
-    static constexpr int value = DEPTH <= 8 ? (LDS ? 256 : 128) : PT_PATH_BLOCK_DEEP;
+    static constexpr int value = DEPTH <= 8 ? (LDS ? PT_PATH_BLOCK_LDS : 128) : PT_PATH_BLOCK_DEEP;
 };
 // LDS = the whole scene lives in LDS for the workgroup's lifetime (Scene::lds_scene: at most
 // kLdsScene nodes, triangles and kLdsMats materials - every scene of the reference): nodes, triangles,
@@ -962,7 +965,7 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), (((MATS & 1) || DEP
     __shared__ uint32_t lds_a[kPathBlock / 64 + 1];
     __shared__ uint32_t lds_b[kPathBlock / 64 + 1];
     __shared__ float4 s_nodes[LDS ? kLdsScene * 4 : 1];
-    __shared__ float4 s_tris[LDS ? kLdsScene * 3 : 1];
+    __shared__ float4 s_tris[(LDS && (MATS & 1)) ? kLdsScene * 3 : 1];
     __shared__ float4 s_shade[LDS ? kLdsScene * 2 : 1];
     __shared__ float4 s_basis[(LDS && !LAST) ? kLdsScene * 3 : 1];
     __shared__ double s_mats[LDS ? kLdsMats * kMatWords : 1];
@@ -1014,10 +1017,10 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), (((MATS & 1) || DEP
             // (the primary bounce walks the eye tables; it needs the general arrays only for shadow rays and uvs)
             constexpr bool kGeneral = !FIRST || NEE || (MATS & 1) || F01;
             if (kGeneral) {
-                // (nodes and eye nodes: plane-major in LDS, pt_traverse.hip.h node_step_lds)
-                for (uint32_t k = threadIdx.x; k < gsc.n_nodes * 16; k += kPathBlock)
-                    reinterpret_cast<float*>(s_nodes)[(k & ~15u) + lds_node_float(k & 15u)] = reinterpret_cast<const float*>(gsc.nodes)[k];
-                for (uint32_t k = threadIdx.x; k < gsc.n_tris * 3; k += kPathBlock) s_tris[k] = gsc.tris[k];
+                // (nodes and eye nodes: plane-major in LDS, pt_traverse.hip.h node_step_lds; Scene::nodes_pm)
+                for (uint32_t k = threadIdx.x; k < gsc.n_nodes * 4; k += kPathBlock) s_nodes[k] = gsc.nodes_pm[k];
+                if (MATS & 1)  // (the vertices: only a textured hit reads them again, the tests start from s_edges)
+                    for (uint32_t k = threadIdx.x; k < gsc.n_tris * 3; k += kPathBlock) s_tris[k] = gsc.tris[k];
             }
             for (uint32_t k = threadIdx.x; k < gsc.n_tris * 2; k += kPathBlock) s_shade[k] = g_shade[k];
             if (!LAST) {
@@ -1030,15 +1033,15 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), (((MATS & 1) || DEP
                 for (uint32_t k = threadIdx.x; k < gsc.n_tris * 7; k += kPathBlock) s_edges[k] = g_ed[k];
             }
             if (FIRST) {
-                const float4* g_en = reinterpret_cast<const float4*>(gsc.eye_nodes);
+                const float4* g_en = gsc.eye_nodes_pm;
                 const float4* g_et = reinterpret_cast<const float4*>(gsc.eye_tris);
-                for (uint32_t k = threadIdx.x; k < gsc.n_nodes * 16; k += kPathBlock)
-                    reinterpret_cast<float*>(s_eye_nodes)[(k & ~15u) + lds_node_float(k & 15u)] = reinterpret_cast<const float*>(g_en)[k];
+                for (uint32_t k = threadIdx.x; k < gsc.n_nodes * 4; k += kPathBlock) s_eye_nodes[k] = g_en[k];
                 for (uint32_t k = threadIdx.x; k < gsc.n_tris * 7; k += kPathBlock) s_eye_tris[k] = g_et[k];
             }
             __syncthreads();
             scene_copied = true;
         }
+        if (PT_CUT(5)) return;  // (diagnostic build: the cost of getting here)
         const uint32_t i = begin + threadIdx.x;
         if (i < end) {
             D3 o = mk(0., 0., 0.), d = o;
