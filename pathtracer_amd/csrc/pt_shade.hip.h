@@ -1061,6 +1061,7 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), (((MATS & 1) || DEP
                 d = mk(in.d[0][i], in.d[1][i], in.d[2][i]);
             }
             const PathRec rec = load_rec<FIRST, NEE>(in, i);  // in flight while the tree is walked
+            if (PT_CUT(6)) { if (d.x == 0.5 && d.y == 0.25) r.lit = true; on_screen = false; }  // (diagnostic build: the ray exists)
             double t = 1.7976931348623157e308;  // ray.rs:22 f64::MAX; t_min = 1e-5 (ray.rs:21)
             uint32_t nn = 0, nt = 0;
             uint32_t leaf = PT_MISS;
@@ -1080,9 +1081,9 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), (((MATS & 1) || DEP
             else if (on_screen)
                 leaf = (FIRST && (LDS || sc.eye_nodes)) ? traverse_eye<DEPTH, kPathBlock, LDS>(sc, d, 1e-5, t, stack + threadIdx.x)
                                                : traverse<DEPTH, false, false, kPathBlock, LDS>(sc, o, d, 1e-5, t, stack + threadIdx.x, nn, nt, top);
-            if (PT_CUT(1)) { if (leaf == 0x7ffffff0u && t == 0.5) r.lit = true; leaf = PT_MISS; on_screen = false; }
+            if (PT_CUT(1) || PT_CUT(6)) { if (leaf == 0x7ffffff0u && t == 0.5) r.lit = true; leaf = PT_MISS; on_screen = false; }
             if (!FIRST) id = slot_id(fr, rec.slot);
-            if (!PT_CUT(1))
+            if (!PT_CUT(1) && !PT_CUT(6))
             shade_vertex<FIRST, LAST, NEE, MATS, true>(sc, fr, bounce, in, i, rec, id, leaf, t, o, d, ls, r);
             if (PT_CUT(2)) r.alive = false;
             // the light sample's visibility, in place: the shadow ray never leaves the registers
