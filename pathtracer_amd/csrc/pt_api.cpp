@@ -107,7 +107,8 @@ struct Workspace {
     Lane lane[2];
     ptd::Sample3 ls;
     DevBuf jitter;
-    uint64_t jitter_cap = 0;
+    uint64_t jitter_cap = 0, tab_cap = 0;  // frames / pixel-table doubles (behind the jitters) the buffer holds
+    uint32_t tab_w = 0, tab_h = 0;         // the image size the pixel table was last filled for
 };
 
 void carve_workspace(Workspace& w, void* base, uint32_t n_slots, uint32_t lane_slots, int n_lanes, bool nee, bool diffs,
@@ -969,7 +970,7 @@ namespace {
 // Enqueues only: no allocation, no host synchronisation (with profiling on, event pairs come from
 // the scene's pool or are created, which is why the no-alloc entry point switches timers off).
 int render_batches(pt_scene* s, const pt_render_params* P, double* accum_dev, hipStream_t st, Workspace& w,
-                   double* jitter, uint32_t spp, bool two, bool nee, bool diffs) {
+                   double* jitter, double* pix_tab, bool fill_tab, uint32_t spp, bool two, bool nee, bool diffs) {
     const uint32_t tw = P->x1 - P->x0, th = owned_rows(P);  // the rows this call renders
     const uint32_t npix = tw * th;
     int rc = PT_OK;
@@ -1040,6 +1041,9 @@ int render_batches(pt_scene* s, const pt_render_params* P, double* accum_dev, hi
         }
     };
 
+    // the screen-space coordinate of every column and row of the image (Frame::pix_ss): `pix_tab`, width + height
+    // doubles, filled here unless the caller knows it to hold this image size already
+    if (pix_tab && fill_tab) ptd::launch_pixel_table(P->width, P->height, pix_tab, st);
     for (uint32_t b0 = 0; b0 < P->sample_count; b0 += spp) {
         const uint32_t ns = std::min(spp, P->sample_count - b0);
         ptd::Frame fr{};
@@ -1063,6 +1067,7 @@ int render_batches(pt_scene* s, const pt_render_params* P, double* accum_dev, hi
         // previous batch's kernels are ahead of this launch on `st`, and a second lane joins `st` below)
         ptd::launch_jitter(P->seed, fr.sample_base, ns, 1. / (double)P->width, 1. / (double)P->height, jitter, st);
         fr.jitter = jitter;
+        fr.pix_ss = pix_tab;
         screen_bounds(s, P->width, P->height, fr);
         ptd::finish_frame(fr);
         // the generate stage is fused into the bounce-0 extend and shade kernels (they rebuild the
@@ -1188,12 +1193,21 @@ int pt_render_device(pt_scene* s, const pt_render_params* P_in, double* accum_de
     if (rc != PT_OK) return rc;
     Workspace& w = s->ws;
     if (two && (rc = ensure_side_stream(s, 2)) != PT_OK) return rc;
-    if (w.jitter_cap < spp) {
+    // the frame jitters, and behind them the pixel table (width + height doubles)
+    const uint64_t tab = (uint64_t)P->width + P->height;
+    if (w.jitter_cap < spp || w.tab_cap < tab) {
         HIP_TRY(hipDeviceSynchronize());  // an earlier call (on any stream) may still read the old buffer
-        HIP_TRY(w.jitter.alloc((size_t)spp * 2 * sizeof(double)));
-        w.jitter_cap = spp;
+        const uint64_t jc = std::max<uint64_t>(w.jitter_cap, spp), tc = std::max(w.tab_cap, tab);
+        HIP_TRY(w.jitter.alloc((size_t)(jc * 2 + tc) * sizeof(double)));
+        w.jitter_cap = jc;
+        w.tab_cap = tc;
+        w.tab_w = w.tab_h = 0;
     }
-    rc = render_batches(s, P, accum_dev, st, w, w.jitter.as<double>(), spp, two, nee, diffs);
+    // (a frame loop of one-frame calls would feel one more launch per call: the table is kept while the image size
+    // stays; calls on other streams are ordered behind the one that filled it by ws_free, like the workspace itself)
+    const bool fill_tab = w.tab_w != P->width || w.tab_h != P->height;
+    rc = render_batches(s, P, accum_dev, st, w, w.jitter.as<double>(), w.jitter.as<double>() + w.jitter_cap * 2, fill_tab, spp, two, nee, diffs);
+    if (rc == PT_OK) { w.tab_w = P->width; w.tab_h = P->height; }
     if (rc != PT_OK) return rc;
     s->stats.samples += n_asked;  // counted once the frames are enqueued, not when a workspace could not be had
     HIP_TRY(hipEventRecord(s->ws_free, st));
@@ -1274,7 +1288,13 @@ int pt_render_device_noalloc(pt_scene* s, const pt_render_params* P_in, double* 
     const bool diffs = (P->flags & PT_FLAG_PROPAGATE_DIFFS) && (P->flags & PT_FLAG_USE_DIFFS) && s->n_texs > 0 &&
                        P->max_bounces > 0;
     // the frame jitters sit in front of the carved workspace
-    const size_t jitter_bytes = ((size_t)kNoAllocJitterFrames * 2 * sizeof(double) + 255) & ~(size_t)255;
+    // ... and behind them the pixel table (width + height doubles)
+    const size_t jitter_only = ((size_t)kNoAllocJitterFrames * 2 * sizeof(double) + 255) & ~(size_t)255;
+    const size_t jitter_bytes = jitter_only + ((((size_t)P->width + P->height) * sizeof(double) + 255) & ~(size_t)255);
+    if (jitter_bytes >= (size_t)PT_NOALLOC_SCRATCH_BYTES) {
+        set_error("an image of %ux%u is too large for the static workspace", P->width, P->height);
+        return PT_ERR_UNSUPPORTED;
+    }
     const size_t room = (size_t)PT_NOALLOC_SCRATCH_BYTES - jitter_bytes;
     auto needed = [&](uint32_t frames) {
         size_t total = 0;
@@ -1309,7 +1329,8 @@ int pt_render_device_noalloc(pt_scene* s, const pt_render_params* P_in, double* 
     // entries and hit records are only read below the counters of the same batch, and the bounce-0
     // kernel stores every word of the radiance bitmap that the batch's accumulate reads.
     s->timers_off = true;   // a HIP-event pair per launch would have to be created: no kernel timing on this path
-    rc = render_batches(s, P, accum_dev, st, w, (double*)base, spp, false, nee, diffs);
+    // (the static array is every scene's on this GPU, and a captured call must stand on its own: the table is filled per call)
+    rc = render_batches(s, P, accum_dev, st, w, (double*)base, (double*)(base + jitter_only), true, spp, false, nee, diffs);
     s->timers_off = false;
     if (rc != PT_OK) return rc;
     if (!capturing) {

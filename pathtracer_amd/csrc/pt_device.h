@@ -253,6 +253,8 @@ struct Frame {  // per-call constants of generate / shade
     uint32_t max_bounces;
     uint32_t flags;
     const double* jitter;  // [n_samples][2] frame jitters, already scaled by the pixel size
+    const double* pix_ss;  // [width + height] screen-space x of every column, y of every row (k_pixel_table: main.rs:412-419
+                           // once per call instead of two f64 divisions per sample), or nullptr
     double diff_size;      // CONFIG.diff_size (PT_FLAG_PROPAGATE_DIFFS)
     // derived by finish_frame(): what every lane would otherwise recompute
     FastDiv div_pixels, div_tile_w;  // / n_tile_pixels, / tile_w
@@ -358,6 +360,7 @@ void launch_accumulate(const Frame& fr, Sample3 lsample, const unsigned long lon
                        Counters* ctr /* nullptr: no statistics */, hipStream_t st);
 // parity entry points
 void launch_build_eye_tables(const Scene& sc, EyeNode* nodes, EyeTri* tris, hipStream_t st);
+void launch_pixel_table(uint32_t width, uint32_t height, double* out, hipStream_t st);  // Frame::pix_ss
 void launch_build_tri_edges(const Scene& sc, EyeTri* tris, hipStream_t st);
 void launch_plane_major(const float* src, float* dst, uint32_t n_nodes, hipStream_t st);  // two-child nodes / EyeNodes -> plane-major
 void launch_build_tri_shade(const Scene& sc, TriShade* out, TriBasis* basis /* or nullptr */, hipStream_t st);

@@ -103,6 +103,9 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const double* __restrict__ a
 // launchers
 static inline uint32_t blocks_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 
+void launch_pixel_table(uint32_t width, uint32_t height, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_pixel_table, dim3(blocks_for(width + height)), dim3(kBlock), 0, st, width, height, out);
+}
 void launch_jitter(uint64_t seed, uint64_t sample_begin, uint32_t n, double psx, double psy, double* out,
                    hipStream_t st) {
     if (!n) return;

@@ -158,6 +158,13 @@ __device__ __forceinline__ PixelArgs pixel_args(uint32_t px, uint32_t py, uint32
     double pixel_ss_y = 1. - 2. * pixel_ndc_y;
     return {(pixel_ss_x + dx) * aspect, pixel_ss_y + dy, 2. * pixel_size_x * aspect, 2. * pixel_size_y};
 }
+// pixel_args through Frame::pix_ss where the call has the table: the same operations, two of them (and both
+// divisions) done once per column / row by k_pixel_table
+__device__ __forceinline__ PixelArgs pixel_args(const Frame& fr, uint32_t px, uint32_t py, double dx, double dy) {
+    if (!fr.pix_ss) return pixel_args(px, py, fr.width, fr.height, dx, dy, fr.aspect);
+    const double pixel_size_x = 1. / (double)fr.width, pixel_size_y = 1. / (double)fr.height;  // (only ray differentials use them)
+    return {(fr.pix_ss[px] + dx) * fr.aspect, fr.pix_ss[fr.width + py] + dy, 2. * pixel_size_x * fr.aspect, 2. * pixel_size_y};
+}
 __device__ __forceinline__ D3 camera_dir(const Camera& c, double x, double y) {
     return normalize(ld3(c.view_dir) + ld3(c.axes0) * x + ld3(c.axes1) * y);
 }

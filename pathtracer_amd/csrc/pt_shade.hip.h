@@ -507,7 +507,7 @@ __device__ __forceinline__ uint32_t compact_wave(bool alive, uint32_t* counter) 
 // be one if the ray fails the triangle test of every emitter.  Such a ray is dropped here, at its
 // producer: it is never queued, read back or traced, and the image is bit-identical.  Non-finite
 // rays and throughputs are kept (NaN * 0 is not 0; the reference accumulates those).
-__device__ __forceinline__ bool finite3(D3 a) { return (a.x - a.x == 0.) && (a.y - a.y == 0.) && (a.z - a.z == 0.); }
+__device__ __forceinline__ bool finite3(D3 a) { return __builtin_isfinite(a.x) && __builtin_isfinite(a.y) && __builtin_isfinite(a.z); }  // (v_cmp_class_f64)
 // The cull may keep a ray that then misses (it is traced and adds nothing), never drop one that hits: so it runs
 // tri_test_core's rejects without its three divisions (a wave of 64 incoherent rays nearly always holds a lane that
 // would need them).  False only where tri_test_core(p, d, 1e-5, f64::MAX) is certain to reject:
@@ -1052,7 +1052,7 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), (((MATS & 1) || DEP
                 const uint32_t gx = fr.x0 + id.tx, gy = id.gy, s = id.s;
                 on_screen = gx >= fr.cx0 && gx < fr.cx1 && gy >= fr.cy0 && gy < fr.cy1;
                 if (on_screen) {
-                    PixelArgs a = pixel_args(gx, gy, fr.width, fr.height, fr.jitter[2 * s], fr.jitter[2 * s + 1], fr.aspect);
+                    PixelArgs a = pixel_args(fr, gx, gy, fr.jitter[2 * s], fr.jitter[2 * s + 1]);
                     o = ld3(sc.cam.eye);
                     d = camera_dir(sc.cam, a.x, a.y);
                 }
@@ -1192,6 +1192,17 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(Frame fr, Sample3 ls, con
 
 // main.rs:402-405 + 469-481 with samples_per_pixel = 1 (main.rs:386): one jitter pair per frame,
 // shared by all pixels; step = 1, x drawn before y, scaled by the pixel size (not twice it).
+// Frame::pix_ss: pixel_args' screen-space coordinate of every column and row, by its own expressions
+__global__ void k_pixel_table(uint32_t width, uint32_t height, double* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < width) {
+        const double pixel_ndc_x = ((double)i + 0.5) / (double)width;
+        out[i] = 2. * pixel_ndc_x - 1.;
+    } else if (i < width + height) {
+        const double pixel_ndc_y = ((double)(i - width) + 0.5) / (double)height;
+        out[i] = 1. - 2. * pixel_ndc_y;
+    }
+}
 __global__ void k_jitter(uint64_t seed, uint64_t sample_begin, uint32_t n, double psx, double psy, double* out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
