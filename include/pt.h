@@ -370,11 +370,12 @@ int pt_accum_device(pt_accum* acc, double** sums_dev, void** stream);
 /* ---- No counterpart in the reference.  pt_render_device for callers that cannot allocate device
  * memory: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same
  * arguments, same result bit for bit; the whole workspace of the call (path queues, hit records,
- * counters, per-sample radiance, frame jitters) is one fixed array of PT_NOALLOC_SCRATCH_BYTES that
+ * counters, per-sample radiance, frame jitters, the table of pixel coordinates) is one fixed array of PT_NOALLOC_SCRATCH_BYTES that
  * lives in the library's code object - every GPU the library runs on holds it from load until the
  * process ends - so the call makes no hipMalloc / hipFree / event or stream creation.  Frames per
  * batch are cut to what fits; PT_ERR_UNSUPPORTED, with the sizes in pt_last_error(), if a single
- * frame of the tile does not fit: 655 360 tile pixels per call (e.g. 1920 x 340), 393 216 with
+ * frame of the tile does not fit: about 655 000 tile pixels inside the scene's screen bounds per call (e.g.
+ * 1920 x 340; the table takes 8 bytes per column and row of the image off the array), 393 000 with
  * PT_FLAG_NEE, 327 680 with PT_FLAG_PROPAGATE_DIFFS on a textured scene (262 144 with both).  No kernel timing on this
  * path (pt_set_profiling level 1 is ignored; the counters of level 2 work).  Every call on a GPU
  * shares that GPU's array.  Calls from two streams, two scenes or two host threads are ORDERED by the
