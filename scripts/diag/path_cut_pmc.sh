@@ -4,7 +4,7 @@
 S=${1:-CornellBox}
 export PT_LIB_PATH=$PWD/pathtracer_amd/lib/alt_pprof.so
 cd /tmp && export TMPDIR=/tmp
-for cut in 5 6 1 2 3 4 0; do
+for cut in ${CUTS:-5 6 1 2 3 4 0}; do
   rm -rf /tmp/pc$cut
   timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES -d /tmp/pc$cut -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/scripts/diag/path_cut_once.py $S $cut > /tmp/pc$cut.log 2>&1 || { tail -5 /tmp/pc$cut.log; exit 1; }
   python3 - $cut <<'PY'
