@@ -164,7 +164,7 @@ struct pt_scene {
     std::vector<pt_bvh_node4> nodes4;  // deep trees: the four-wide device tree
     uint32_t stack_need = 0;           // entries the deepest path of the device tree needs
     DevBuf d_nodes4;
-    DevBuf d_nodes, d_tris, d_uvs, d_leaf_of, d_mats, d_texs, d_lights, d_emissive, d_prims, d_tri_shade, d_tri_basis, d_eye_nodes, d_eye_tris, d_tri_edges, d_nodes_pm, d_eye_nodes_pm, d_ctr;
+    DevBuf d_nodes, d_tris, d_uvs, d_leaf_of, d_mats, d_texs, d_lights, d_emissive, d_prims, d_tri_shade, d_tri_basis, d_eye_nodes, d_eye_tris, d_tri_edges, d_lds_image, d_ctr;
     std::vector<DevBuf*> d_texels;
     Workspace ws;
     std::mutex mu;
@@ -789,19 +789,30 @@ static int scene_create_impl(const pt_scene_desc* d, int device_id, const pt_sce
     dv.lds_scene = dv.eye_nodes && dv.n_nodes <= (uint32_t)ptd::kLdsScene && d->n_tris <= (uint32_t)ptd::kLdsScene &&
                    d->n_mats <= (uint32_t)ptd::kLdsMats && d->n_prims == 0 && opt(o.lds_scene, true);
     dv.tri_edges = nullptr;
-    dv.nodes_pm = dv.eye_nodes_pm = nullptr;
+    dv.lds_image = nullptr;
     if (dv.lds_scene) {
         HIP_TRY(s->d_tri_edges.alloc((size_t)d->n_tris * sizeof(ptd::EyeTri)));
         ptd::launch_build_tri_edges(dv, s->d_tri_edges.as<ptd::EyeTri>(), nullptr);
         dv.tri_edges = s->d_tri_edges.as<ptd::EyeTri>();
-        // the nodes as the path kernel keeps them in LDS
-        static_assert(sizeof(ptd::EyeNode) == 64 && sizeof(pt_bvh_node) == 64, "two-child nodes: 16 floats");
-        HIP_TRY(s->d_nodes_pm.alloc(s->nodes.size() * 64));
-        HIP_TRY(s->d_eye_nodes_pm.alloc(s->nodes.size() * 64));
-        ptd::launch_plane_major(reinterpret_cast<const float*>(dv.nodes), s->d_nodes_pm.as<float>(), dv.n_nodes, nullptr);
-        ptd::launch_plane_major(reinterpret_cast<const float*>(dv.eye_nodes), s->d_eye_nodes_pm.as<float>(), dv.n_nodes, nullptr);
-        dv.nodes_pm = s->d_nodes_pm.as<float4>();
-        dv.eye_nodes_pm = s->d_eye_nodes_pm.as<float4>();
+        // everything the path kernel keeps in LDS, in one array at fixed offsets (ptd::kImg...)
+        static_assert(sizeof(ptd::EyeNode) == 64 && sizeof(pt_bvh_node) == 64 && sizeof(ptd::EyeTri) == 112 &&
+                      sizeof(ptd::TriShade) == 32 && sizeof(ptd::TriBasis) == 48, "table strides of the LDS image");
+        HIP_TRY(s->d_lds_image.alloc((size_t)ptd::kImgEnd * 16));
+        HIP_TRY(hipMemset(s->d_lds_image.p, 0, (size_t)ptd::kImgEnd * 16));
+        char* img = static_cast<char*>(s->d_lds_image.p);
+        auto put = [&](int at, const void* src, size_t bytes) {
+            return bytes ? hipMemcpy(img + (size_t)at * 16, src, bytes, hipMemcpyDeviceToDevice) : hipSuccess;
+        };
+        HIP_TRY(hipDeviceSynchronize());  // the tables above were built on the null stream
+        HIP_TRY(put(ptd::kImgShade, dv.tri_shade, (size_t)d->n_tris * sizeof(ptd::TriShade)));
+        HIP_TRY(put(ptd::kImgMats, dv.mats, (size_t)d->n_mats * sizeof(ptd::Material)));
+        HIP_TRY(put(ptd::kImgBasis, dv.tri_basis, (size_t)d->n_tris * sizeof(ptd::TriBasis)));
+        HIP_TRY(put(ptd::kImgEyeTris, dv.eye_tris, (size_t)d->n_tris * sizeof(ptd::EyeTri)));
+        HIP_TRY(put(ptd::kImgEdges, dv.tri_edges, (size_t)d->n_tris * sizeof(ptd::EyeTri)));
+        HIP_TRY(put(ptd::kImgTris, dv.tris, (size_t)d->n_tris * 48));
+        ptd::launch_plane_major(reinterpret_cast<const float*>(dv.eye_nodes), reinterpret_cast<float*>(img + (size_t)ptd::kImgEyeNodes * 16), dv.n_nodes, nullptr);
+        ptd::launch_plane_major(reinterpret_cast<const float*>(dv.nodes), reinterpret_cast<float*>(img + (size_t)ptd::kImgNodes * 16), dv.n_nodes, nullptr);
+        dv.lds_image = reinterpret_cast<const float4*>(img);
     }
     HIP_TRY(hipDeviceSynchronize());
     for (int a = 0; a < 3; ++a) dv.background[a] = d->background[a];

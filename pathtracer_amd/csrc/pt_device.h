@@ -86,6 +86,20 @@ struct EyeTri {
 constexpr uint32_t kEyeTableMaxTris = 1u << 16;
 constexpr uint32_t kMaxCullEmitters = 8;
 constexpr int kLdsScene = 32, kLdsMats = 16;  // nodes / triangles / materials of a scene that the fused kernel holds in LDS
+// Scene::lds_image: everything such a kernel keeps in LDS as ONE array of float4, every table at a fixed offset and
+// padded to kLdsScene / kLdsMats entries, built once per scene - the kernel's copy is one loop over a prefix (two
+// ranges for a kernel that does not trace primary rays) instead of one loop per table.  Order: what every kernel
+// needs, the primary rays' tables, the tables of rays from anywhere, the vertices (textured scenes only).
+constexpr int kImgShade = 0;                                                        // TriShade[kLdsScene]
+constexpr int kImgMats = kImgShade + kLdsScene * 2;                                 // Material[kLdsMats]
+constexpr int kImgBasis = kImgMats + kLdsMats * (int)(sizeof(Material) / 16);       // TriBasis[kLdsScene]
+constexpr int kImgEyeNodes = kImgBasis + kLdsScene * 3;                             // EyeNode[kLdsScene], plane-major
+constexpr int kImgEyeTris = kImgEyeNodes + kLdsScene * 4;                           // EyeTri[kLdsScene]
+constexpr int kImgNodes = kImgEyeTris + kLdsScene * 7;                              // nodes, plane-major
+constexpr int kImgEdges = kImgNodes + kLdsScene * 4;                                // EyeTri[kLdsScene] of the origin (tri_edges)
+constexpr int kImgTris = kImgEdges + kLdsScene * 7;                                 // float4 x 3 [kLdsScene]
+constexpr int kImgEnd = kImgTris + kLdsScene * 3;
+static_assert(sizeof(Material) % 16 == 0, "materials as float4s");
 // An emissive triangle as the last-bounce cull tests it: the origin-independent part of the
 // triangle test (v0, e0, e1, e0 x e1 in f64), computed once on the device by the test's own code.
 struct EmitTri {
@@ -124,8 +138,8 @@ struct Scene {
     const EyeTri* eye_tris;
     const EyeTri* tri_edges;    // the same records for the origin (0, 0, 0): e0, e1, e0 x e1 and vo = v0 of every triangle, for
                                 // rays from anywhere (scenes that live in LDS: a ds_read instead of 24 f64 operations per test)
-    const float4* nodes_pm;     // scenes that live in LDS: `nodes` and `eye_nodes` plane-major (pt_traverse.hip.h node_step_lds),
-    const float4* eye_nodes_pm; // 4 x float4 a node, what the path kernel copies into LDS as it is
+    const float4* lds_image;    // scenes that live in LDS: all their tables as the path kernel keeps them (kImg..., kImgEnd float4s;
+                                // the nodes and eye nodes plane-major, pt_traverse.hip.h node_step_lds)
     const uint32_t* leaf_of;  // global triangle id -> leaf-order index
     const Material* mats;
     const Texture* texs;

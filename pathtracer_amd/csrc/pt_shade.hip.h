@@ -964,28 +964,24 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), (((MATS & 1) || DEP
     if (DEPTH > 8 && kTopNodes > 0) top = load_top_nodes<kPathBlock>(gsc, s_top);
     __shared__ uint32_t lds_a[kPathBlock / 64 + 1];
     __shared__ uint32_t lds_b[kPathBlock / 64 + 1];
-    __shared__ float4 s_nodes[LDS ? kLdsScene * 4 : 1];
-    __shared__ float4 s_tris[(LDS && (MATS & 1)) ? kLdsScene * 3 : 1];
-    __shared__ float4 s_shade[LDS ? kLdsScene * 2 : 1];
-    __shared__ float4 s_basis[(LDS && !LAST) ? kLdsScene * 3 : 1];
-    __shared__ double s_mats[LDS ? kLdsMats * kMatWords : 1];
-    __shared__ float4 s_eye_nodes[(LDS && FIRST) ? kLdsScene * 4 : 1];
-    __shared__ float4 s_eye_tris[(LDS && FIRST) ? kLdsScene * 7 : 1];
+    // the scene in LDS: one array, Scene::lds_image's layout (pt_device.h kImg...); a kernel allocates the prefix it needs
     constexpr bool kEdges = LDS && (!FIRST || NEE || F01);  // some ray of this kernel is traced by traverse()
-    __shared__ float4 s_edges[kEdges ? kLdsScene * 7 : 1];
-    static_assert(sizeof(TriShade) == 32 && sizeof(TriBasis) == 48 && sizeof(EyeNode) == 64 && sizeof(EyeTri) == 112 && sizeof(Material) % 8 == 0, "LDS copies");
+    constexpr bool kVerts = LDS && (MATS & 1);              // a textured hit reads its vertices again
+    constexpr int kImgUsed = !LDS ? 1 : (kVerts ? kImgEnd : (kEdges ? kImgTris : kImgNodes));
+    __shared__ float4 s_img[kImgUsed];
+    static_assert(sizeof(TriShade) == 32 && sizeof(TriBasis) == 48 && sizeof(EyeNode) == 64 && sizeof(EyeTri) == 112 && sizeof(Material) % 16 == 0, "LDS copies");
     Scene sc = gsc;
     if (LDS) {  // pointers first (compile-time: the address space is then known at every use), data below
-        sc.nodes = s_nodes;
-        sc.tris = s_tris;
-        sc.tri_shade = reinterpret_cast<const TriShade*>(s_shade);
-        if (!LAST) sc.tri_basis = reinterpret_cast<const TriBasis*>(s_basis);  // (an LDS scene always has the table)
-        sc.mats = reinterpret_cast<const Material*>(s_mats);
+        sc.nodes = s_img + kImgNodes;      // (plane-major: node_step_lds)
+        sc.tris = s_img + (kVerts ? kImgTris : 0);
+        sc.tri_shade = reinterpret_cast<const TriShade*>(s_img + kImgShade);
+        if (!LAST) sc.tri_basis = reinterpret_cast<const TriBasis*>(s_img + kImgBasis);  // (an LDS scene always has the table)
+        sc.mats = reinterpret_cast<const Material*>(s_img + kImgMats);
         if (FIRST) {
-            sc.eye_nodes = reinterpret_cast<const EyeNode*>(s_eye_nodes);
-            sc.eye_tris = reinterpret_cast<const EyeTri*>(s_eye_tris);
+            sc.eye_nodes = reinterpret_cast<const EyeNode*>(s_img + kImgEyeNodes);
+            sc.eye_tris = reinterpret_cast<const EyeTri*>(s_img + kImgEyeTris);
         }
-        if (kEdges) sc.tri_edges = reinterpret_cast<const EyeTri*>(s_edges);
+        if (kEdges) sc.tri_edges = reinterpret_cast<const EyeTri*>(s_img + kImgEdges);
     }
     bool scene_copied = false;
     if (ctr && blockIdx.x == 0 && threadIdx.x == 0)
@@ -1012,32 +1008,10 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), (((MATS & 1) || DEP
         }
         if (begin >= end) return;
         if (LDS && !scene_copied) {  // block-uniform: every thread of a live block gets here
-            const float4* g_shade = reinterpret_cast<const float4*>(gsc.tri_shade);
-            const double* g_mats = reinterpret_cast<const double*>(gsc.mats);
-            // (the primary bounce walks the eye tables; it needs the general arrays only for shadow rays and uvs)
-            constexpr bool kGeneral = !FIRST || NEE || (MATS & 1) || F01;
-            if (kGeneral) {
-                // (nodes and eye nodes: plane-major in LDS, pt_traverse.hip.h node_step_lds; Scene::nodes_pm)
-                for (uint32_t k = threadIdx.x; k < gsc.n_nodes * 4; k += kPathBlock) s_nodes[k] = gsc.nodes_pm[k];
-                if (MATS & 1)  // (the vertices: only a textured hit reads them again, the tests start from s_edges)
-                    for (uint32_t k = threadIdx.x; k < gsc.n_tris * 3; k += kPathBlock) s_tris[k] = gsc.tris[k];
-            }
-            for (uint32_t k = threadIdx.x; k < gsc.n_tris * 2; k += kPathBlock) s_shade[k] = g_shade[k];
-            if (!LAST) {
-                const float4* g_basis = reinterpret_cast<const float4*>(gsc.tri_basis);
-                for (uint32_t k = threadIdx.x; k < gsc.n_tris * 3; k += kPathBlock) s_basis[k] = g_basis[k];
-            }
-            for (uint32_t k = threadIdx.x; k < gsc.n_mats * kMatWords; k += kPathBlock) s_mats[k] = g_mats[k];
-            if (kEdges) {
-                const float4* g_ed = reinterpret_cast<const float4*>(gsc.tri_edges);
-                for (uint32_t k = threadIdx.x; k < gsc.n_tris * 7; k += kPathBlock) s_edges[k] = g_ed[k];
-            }
-            if (FIRST) {
-                const float4* g_en = gsc.eye_nodes_pm;
-                const float4* g_et = reinterpret_cast<const float4*>(gsc.eye_tris);
-                for (uint32_t k = threadIdx.x; k < gsc.n_nodes * 4; k += kPathBlock) s_eye_nodes[k] = g_en[k];
-                for (uint32_t k = threadIdx.x; k < gsc.n_tris * 7; k += kPathBlock) s_eye_tris[k] = g_et[k];
-            }
+            // the prefix of the image this kernel reads; one that traces no primary rays skips their tables
+            constexpr int kSkipFrom = FIRST ? kImgUsed : kImgEyeNodes, kSkipTo = FIRST ? kImgUsed : kImgNodes;
+            for (int k = threadIdx.x; k < kSkipFrom; k += kPathBlock) s_img[k] = gsc.lds_image[k];
+            for (int k = kSkipTo + threadIdx.x; k < kImgUsed; k += kPathBlock) s_img[k] = gsc.lds_image[k];
             __syncthreads();
             scene_copied = true;
         }
