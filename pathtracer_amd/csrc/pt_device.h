@@ -344,6 +344,10 @@ constexpr int kWideLds = 16, kWideSpill = 48, kWideStack = kWideLds + kWideSpill
 #define PT_TOP_NODES 21
 #endif
 constexpr int kTopNodes = PT_TOP_NODES;
+#ifndef PT_PATH_TOP
+#define PT_PATH_TOP 5
+#endif
+constexpr int kPathTopNodes = PT_PATH_TOP;  // ... and by the deep-tree path kernel (k_path), one walk per workgroup: two levels
 constexpr int kBlock = 256;
 constexpr int kTravBlock = 64;  // extend / shadow: one wave per workgroup, LDS and registers are released per wave
 

@@ -959,9 +959,14 @@ __global__ __launch_bounds__((PathBlock<DEPTH, LDS>::value), (((MATS & 1) || DEP
     static_assert(!F01 || (FIRST && !LAST && LDS), "the two-bounce form is the primary launch of a scene in LDS");
     constexpr int kPathBlock = PathBlock<DEPTH, LDS>::value;
     __shared__ int stack[DEPTH * kPathBlock];
-    __shared__ float4 s_top[(DEPTH > 8 && kTopNodes > 0) ? kTopNodes * 8 : 1];
+    // The deep-tree path kernel runs one 64-ray workgroup per wave, so every wave pays the copy of the tree's top for
+    // the one walk it does: the root and its four children (kPathTopNodes = 5) instead of the extend kernel's three
+    // levels (kTopNodes = 21, copied once per persistent wave): primary kernel -8 % (0 / 1 / 5 / 9 / 21 nodes:
+    // 1418 / 1391 / 1358 / 1444 / 1477 ms per 128 launches), heightfield +2.7 %.
+    constexpr int kPathTop = PT_PATH_TOP < kTopNodes ? PT_PATH_TOP : kTopNodes;
+    __shared__ float4 s_top[(DEPTH > 8 && kPathTop > 0) ? kPathTop * 8 : 1];
     TopNodes top{nullptr, 0};
-    if (DEPTH > 8 && kTopNodes > 0) top = load_top_nodes<kPathBlock>(gsc, s_top);
+    if (DEPTH > 8 && kPathTop > 0) top = load_top_nodes<kPathBlock, kPathTop>(gsc, s_top);
     __shared__ uint32_t lds_a[kPathBlock / 64 + 1];
     __shared__ uint32_t lds_b[kPathBlock / 64 + 1];
     // the scene in LDS: one array, Scene::lds_image's layout (pt_device.h kImg...); a kernel allocates the prefix it needs

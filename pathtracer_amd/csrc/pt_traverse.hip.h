@@ -297,9 +297,9 @@ struct WideStack {
     TopNodes top;
 };
 // all threads of the workgroup, before any of them leaves; BLOCK threads
-template <int BLOCK>
+template <int BLOCK, int MAX = kTopNodes>
 __device__ __forceinline__ TopNodes load_top_nodes(const Scene& sc, float4* s_top) {
-    const int n = min((int)sc.n_top, kTopNodes);
+    const int n = min((int)sc.n_top, MAX);
     for (int k = threadIdx.x; k < n * 8; k += BLOCK) s_top[k] = sc.nodes4[k];
     __syncthreads();
     return TopNodes{(LdsF4)(V4f*)s_top, n};
