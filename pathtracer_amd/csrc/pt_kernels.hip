@@ -46,7 +46,7 @@ __global__ void k_sample_brdf(Scene sc, Frame fr, uint32_t bounce, const double*
     const Material& m = sc.mats[mat];
     uint32_t pixel = pixel_in[i];
     D3 diffuse = mk(0., 0., 0.);
-    if (m.kind == PT_MAT_LAMBERT) diffuse = diffuse_of(sc, m, leaf, o, d, position, normal, fr, bounce == 0, pixel, 0);
+    if (m.kind == PT_MAT_LAMBERT) diffuse = diffuse_of(sc, m, leaf, o, d, position, normal, fr, bounce == 0, pixel % fr.width, pixel / fr.width, 0);
     double xi1, xi2;
     uniform2(fr.seed, pixel, fr.sample_base, bounce, STREAM_BRDF, xi1, xi2);
     Brdf bs;

@@ -444,26 +444,27 @@ __device__ __forceinline__ void hit_geometry(const Scene& sc, uint32_t leaf, D3 
     normal = ld3(ts.n);
 }
 // scene.rs:47-54: the differential rays of the camera ray of `pixel` in frame `s` of the batch
-__device__ __forceinline__ RayDiffs camera_diffs(const Scene& sc, const Frame& fr, D3 eye, uint32_t pixel, uint32_t s) {
-    PixelArgs a = pixel_args(pixel % fr.width, pixel / fr.width, fr.width, fr.height, fr.jitter[2 * s],
-                             fr.jitter[2 * s + 1], fr.aspect);
+// (gx, gy: the pixel's column and row in the image - the caller has them, a division of the pixel index by the width
+// costs ~50 instructions; the pixel table where the call has one)
+__device__ __forceinline__ RayDiffs camera_diffs(const Scene& sc, const Frame& fr, D3 eye, uint32_t gx, uint32_t gy, uint32_t s) {
+    PixelArgs a = pixel_args(fr, gx, gy, fr.jitter[2 * s], fr.jitter[2 * s + 1]);
     return {eye, eye, camera_dir(sc.cam, a.x + a.ddx, a.y), camera_dir(sc.cam, a.x, a.y + a.ddy)};
 }
 __device__ __forceinline__ D3 diffuse_of(const Scene& sc, const Material& m, uint32_t leaf, D3 o,
                                          D3 d, D3 position, D3 normal, const Frame& fr, bool primary,
-                                         uint32_t pixel, uint32_t s) {
+                                         uint32_t gx, uint32_t gy, uint32_t s) {
     if (m.tex < 0) return ld3(m.color);
     bool has_dp = false;
     D3 dpdx = mk(0., 0., 0.), dpdy = dpdx;
     if (leaf >= PT_PRIM_BASE) {
         const Prim& pr = sc.prims[leaf - PT_PRIM_BASE];
         if (pr.kind == PT_PRIM_SPHERE && primary && (fr.flags & PT_FLAG_USE_DIFFS))
-            has_dp = surface_dp(normal, position, camera_diffs(sc, fr, o, pixel, s), dpdx, dpdy);
+            has_dp = surface_dp(normal, position, camera_diffs(sc, fr, o, gx, gy, s), dpdx, dpdy);
         return prim_textured_color(sc, m, pr, position, normal, has_dp, dpdx, dpdy);
     }
     const TriV tr = load_tri(sc, leaf);  // only a textured hit needs the vertices again (uv, dpdu, dpdv)
     if (primary && (fr.flags & PT_FLAG_USE_DIFFS))
-        has_dp = surface_dp(normal, position, camera_diffs(sc, fr, o, pixel, s), dpdx, dpdy);
+        has_dp = surface_dp(normal, position, camera_diffs(sc, fr, o, gx, gy, s), dpdx, dpdy);
     return textured_color(sc, m, tr, leaf, o, d, normal, has_dp, dpdx, dpdy);
 }
 
@@ -648,7 +649,7 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
             bool curved = false;
             if (DIFFS) {  // surface.rs:59-84 for the ray's own differentials, at every vertex
                 if (FIRST) {
-                    inc_diff = camera_diffs(sc, fr, o, pixel, s);
+                    inc_diff = camera_diffs(sc, fr, o, fr.x0 + tx, gy_, s);
                 } else {
                     const double* q = in.diff + i;
                     const size_t st = in.diff_stride;
@@ -675,7 +676,7 @@ __device__ __forceinline__ void shade_vertex(const Scene& sc, const Frame& fr, u
                     else diffuse = textured_color(sc, m, load_tri(sc, leaf), leaf, o, d, normal, has_dp, dpdx, dpdy);
                 }
             } else if (!SPEC || m.kind == PT_MAT_LAMBERT) {
-                diffuse = TEX ? diffuse_of(sc, m, leaf, o, d, position, normal, fr, FIRST, pixel, s) : ld3(m.color);
+                diffuse = TEX ? diffuse_of(sc, m, leaf, o, d, position, normal, fr, FIRST, fr.x0 + tx, gy_, s) : ld3(m.color);
             }
             if (ref_lights) {
                 // EstimateDirect (lights.rs:110-137) over AreaLight::sample (lights.rs:42-62) and

@@ -17,10 +17,13 @@ if name == "heightfield":
     from pathtracer_amd.synthetic import heightfield_box
     scene = pt.Scene(heightfield_box(), 0)
     cfg = pt.Config(width=3840, height=2160, bounces=2, seed=1, spp_per_batch=64)
+elif name == "Test_textured":
+    scene = pt.Scene(pt.scene_data("Test", textures=True), 0)
+    cfg = pt.Config(width=3840, height=2160, bounces=2, seed=1, spp_per_batch=16)
 else:
     scene = pt.Scene(pt.scene_data(name), 0)
     cfg = pt.Config(width=1920, height=1080, bounces=2, seed=1, spp_per_batch=64)
 acc = torch.zeros((cfg.h, cfg.w, 3), dtype=torch.float64, device="cuda")
 assert fn(cut) == 0
-scene.render_device(cfg, acc.data_ptr(), 0, 64)
+scene.render_device(cfg, acc.data_ptr(), 0, cfg.spp_per_batch or 64)
 torch.cuda.synchronize()
