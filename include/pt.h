@@ -287,7 +287,9 @@ void pt_scene_options_from_env(pt_scene_options* options);
 
 /* ---- scene.rs:140-193 + bvh.rs:17-21: build the device-resident scene on HIP device `device_id`.
  * pt_scene_create_ex takes the scheduling options of this scene (NULL = all defaults) and never reads the
- * environment; pt_scene_create is pt_scene_create_ex with pt_scene_options_from_env's options. */
+ * environment; pt_scene_create is pt_scene_create_ex with pt_scene_options_from_env's options.
+ * Size limits (PT_ERR_UNSUPPORTED beyond): 2^28 triangles (leaf references), 2^25 four-wide nodes of a deep tree
+ * (the traversal addresses a node through a 32-bit byte offset) - about 10^8 triangles at two per leaf. */
 int pt_scene_create_ex(const pt_scene_desc* desc, int device_id, const pt_scene_options* options, pt_scene** out);
 int pt_scene_create(const pt_scene_desc* desc, int device_id, pt_scene** out);
 void pt_scene_destroy(pt_scene* scene);
